@@ -1,0 +1,136 @@
+/*
+ * w2c_hip.h -- C ABI of libw2c_hip.so: the MI355X (gfx950) kernels under the
+ * When2com forward path of GT-RIPL/MultiAgentPerception.
+ *
+ * The reference has no FFI: its boundary is the Python package path
+ * ptsemseg.models (get_model -> nn.Module.forward, models/__init__.py:8-86).
+ * This library sits UNDER that boundary.  Each entry point replaces the stock
+ * torch.nn call(s) the reference module bottoms out in; the reference
+ * file:line each one stands in for is cited per function.  Plain pointers and
+ * sizes only -- no torch types.  Every pointer is a DEVICE pointer on the
+ * current HIP device unless stated; `stream` is a hipStream_t passed as void*.
+ * All functions are re-entrant, keep no global mutable state, launch
+ * asynchronously on `stream` and return 0 (W2C_OK) or a negative W2C_E_* code
+ * (never abort).  w2c_status_string() maps a code to text.
+ *
+ * Data layout inside the path: activations are bf16 NHWC ("pixel-major":
+ * [image][y][x][channel]) with an explicit per-pixel channel stride so that
+ * the u_encoder trunk and the query_key_net trunk (same shapes, different
+ * weights) live channel-interleaved in ONE tensor and run as a 2-group conv.
+ * Images are agent-major: row = agent * B + sample (agent.py:1105-1108).
+ * bf16 values are passed as uint16_t.
+ */
+#ifndef W2C_HIP_H
+#define W2C_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2C_OK 0
+#define W2C_E_ARG (-1)    /* invalid argument / unsupported shape */
+#define W2C_E_LAUNCH (-2) /* HIP launch error (hipGetLastError) */
+
+typedef void* w2c_stream_t;
+
+int w2c_version(void);
+const char* w2c_status_string(int code);
+/* name of the device the calling thread is on, gcnArchName (e.g. "gfx950:...") */
+int w2c_device_arch(char* buf, int buflen);
+
+/* ---- a3 + K1: divide_inputs/cat (agent.py:1088-1096,1105-1108) fused with
+ * resnet conv1 7x7/2 p3 (no bias) + bn1 + relu (backbone.py:65-66,76-80).
+ * x   : f32 [B, 3*N, H, W] (NCHW, agent i in channels 3i..3i+2)
+ * w   : bf16 [Cout][7 ky][8 kx][4 ci]  (kx==7 and ci==3 are zero padding)
+ * scale/shift : f32 [Cout]  (eval BN folded: y = relu(conv * scale + shift))
+ * y   : bf16 NHWC [N*B, H/2, W/2, Cout], agent-major.  Cout in {64, 128}
+ *       (128 = both trunks' stems side by side).  H, W multiples of 32. */
+int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int W,
+                             const uint16_t* w, const float* scale, const float* shift, int Cout,
+                             uint16_t* y, w2c_stream_t stream);
+
+/* ---- K1b: maxpool 3x3 s2 p1 (backbone.py:66 via resnet.maxpool), bf16 NHWC.
+ * x [M, H, W, C] -> y [M, H/2, W/2, C]; C multiple of 8. */
+int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, w2c_stream_t stream);
+
+/* ---- K2/K3/K4/K8: conv (3x3 p1 or 1x1 p0, stride 1|2) as an MFMA implicit
+ * GEMM, with the eval-mode BatchNorm / bias folded into a per-channel f32
+ * scale/shift epilogue, optional residual add, optional ReLU.  Stands in for
+ * nn.Conv2d+BatchNorm2d+ReLU (models/utils.py:87-120), the BasicBlock convs
+ * and 1x1 downsample (backbone.py:66-69 via the third-party resnet18) and the
+ * decoder convs (backbone.py:150-154).
+ * x        : bf16 NHWC, pixel stride x_cstride elements; group g reads
+ *            channels [g*Cin, (g+1)*Cin)
+ * w        : bf16 [groups][Cout][ksize*ksize][Cin]
+ * scale, shift : f32 [groups*Cout]
+ * residual : bf16, same geometry as y (nullable)
+ * y        : bf16 (y_is_f32=0) or f32 (y_is_f32=1) NHWC, pixel stride
+ *            y_cstride; group g writes channels [g*Cout, (g+1)*Cout)
+ * zero_page: >= 256 bytes of zeros (source for padded taps)
+ * Cin multiple of 64; Cout multiple of 32. */
+int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                        const uint16_t* w, int Cout, int ksize, int stride, int groups,
+                        const float* scale, const float* shift,
+                        const uint16_t* residual, int relu,
+                        void* y, int y_cstride, int y_is_f32,
+                        const void* zero_page, w2c_stream_t stream);
+
+/* ---- K5: Linear (+ReLU) for the key/query heads (agent.py:150-159,167-178).
+ * x : [M, K] bf16 (x_is_bf16=1, row stride x_stride elements) or f32
+ * w : f32 [O, K] row-major; b : f32 [O]; y : f32 [M, O].  K multiple of 4, M <= 64 per call. */
+int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M, int K,
+                   const float* w, const float* b, int O, int relu, float* y, w2c_stream_t stream);
+
+/* ---- K6: communication graph.  MIMOGeneralDotProductAttention scores +
+ * softmax over keys (agent.py:256,268,274), the +0.001*I tie-break
+ * (agent.py:1164-1167) and the argmax_select / activated_select coefficient
+ * transforms (agent.py:1036-1078); with who=1 the diagonal is masked as in
+ * MIMOWhoGeneralDotProductAttention (agent.py:299-343) and no tie-break is added.
+ * query : f32 [q_n*B, Dq], row (q-q_lo)*B+b, for the produced query agents only
+ *         (NULL => all-ones queries, agent.py:1143,1370)
+ * key   : f32 [N*B, Dk] agent-major
+ * wq, bq: attention_net.linear weight [Dk, Dq] / bias [Dk]
+ * mode  : 0 softmax, 1 argmax_test, 2 activated (thres)
+ * q_lo, q_n : only query agents [q_lo, q_lo+q_n) are produced (agent-parallel
+ *             ranks own a slice of the queries; keys are always all N)
+ * workspace : f32 scratch, N*B*(Dq+1) floats (the projected keys Wq^T key, key.bq)
+ * prob  : f32 [B, N, q_n]  returned prob_action columns
+ * coef  : f32 [B, N, q_n]  fusion coefficients for the returned prediction
+ * action: i64 [B, q_n]
+ * nnz_offdiag : i32 [B]    off-diagonal non-zeros of coef per sample (num_connect numerator) */
+int w2c_comm_graph(const float* query, const float* key, const float* wq, const float* bq,
+                   int B, int N, int Dq, int Dk, int who, int mode, float thres, float tie_bias,
+                   int q_lo, int q_n, float* workspace,
+                   float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                   w2c_stream_t stream);
+
+/* ---- K7 + a10: attention-weighted fusion (agent.py:276-284) fused with
+ * agents2batch (agent.py:1080-1086).
+ * v    : bf16 NHWC rows [N*B][hw][v_cstride], agent-major, C channels used
+ * coef : f32 [B, N, q_n]
+ * out  : bf16 NHWC rows [q_n*B][hw][out_cstride]: row (q*B+b) channels
+ *        [0,C) = sum_k coef[b,k,q] * v[k*B+b]; with append_own=1 channels
+ *        [C,2C) = v[(q_lo+q)*B+b] (MIMOcomWho cat, agent.py:1382). */
+int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, int N, int q_lo, int q_n,
+                    int hw, int C, int append_own, uint16_t* out, int out_cstride, w2c_stream_t stream);
+
+/* ---- K9: bilinear x32 upsample, align_corners=False (backbone.py:160).
+ * low : f32 NHWC [M, h, w, low_cstride] (first n_classes channels used)
+ * out : f32 NCHW [M, n_classes, 32h, 32w] */
+int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstride, int n_classes,
+                            float* out, w2c_stream_t stream);
+
+/* ---- helpers at the boundary ---- */
+/* f32 NCHW [M,C,H,W] -> bf16 NHWC [M,H,W,cstride] (channels [0,C)); used by tests and the
+ * Single-kernel parity harness, not by the forward path. */
+int w2c_nchw_f32_to_nhwc_bf16(const float* x, int M, int C, int H, int W, uint16_t* y, int y_cstride,
+                              w2c_stream_t stream);
+int w2c_nhwc_bf16_to_nchw_f32(const uint16_t* x, int x_cstride, int M, int C, int H, int W, float* y,
+                              w2c_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2C_HIP_H */

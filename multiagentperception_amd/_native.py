@@ -1,0 +1,63 @@
+"""ctypes binding of libw2c_hip.so (C ABI declared in include/w2c_hip.h).
+
+The library is REQUIRED: there is no CPU or PyTorch fallback.  Importing this
+module never fails (so host-only tooling can import the package), but the first
+use of ``lib()`` raises if the shared object is missing or does not export every
+declared symbol.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libw2c_hip.so")
+
+_c = ctypes
+_vp, _i, _f = _c.c_void_p, _c.c_int, _c.c_float
+
+# symbol -> argtypes (restype is int unless noted); mirrors include/w2c_hip.h
+SIGNATURES = {
+    "w2c_version": [],
+    "w2c_status_string": [_i],
+    "w2c_device_arch": [_c.c_char_p, _i],
+    "w2c_stem_conv7x7_bn_relu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "w2c_maxpool3x3s2": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
+    "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
+    "w2c_comm_graph": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "w2c_fuse_values": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "w2c_nchw_f32_to_nhwc_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp],
+    "w2c_nhwc_bf16_to_nchw_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+}
+
+_lib = None
+
+
+class W2CError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise W2CError(
+                "libw2c_hip.so not found at %s -- build it with "
+                "`python -m multiagentperception_amd._build` (needs hipcc, gfx950). "
+                "There is no CPU fallback for the When2com forward path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise W2CError("libw2c_hip.so does not export %s (stale build?)" % name)
+            fn.argtypes = argtypes
+            fn.restype = _c.c_char_p if name == "w2c_status_string" else _i
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().w2c_status_string(code)
+        raise W2CError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

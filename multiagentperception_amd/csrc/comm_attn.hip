@@ -1,0 +1,275 @@
+// comm_attn.hip -- K5 (key/query heads), K6 (communication graph) and K7 (feature fusion).
+//
+//  K5  w2c_linear_f32      km_generator / linear MLP layers (agent.py:150-159, 167-178)
+//  K6  w2c_comm_graph      MIMOGeneralDotProductAttention scores + softmax over KEYS
+//                          (agent.py:256,268,274), +0.001*I tie-break (agent.py:1164-1167),
+//                          argmax_select / activated_select coefficients (agent.py:1036-1078),
+//                          and the diagonal-masked variant of MIMOcomWho (agent.py:299-343)
+//  K7  w2c_fuse_values     sum_k coef[b,k,q] * V[b,k] (agent.py:276-284) + agents2batch
+//                          (agent.py:1080-1086), without the reference's [B,Nk,Nq,C,h,w] temporary
+//
+// These are latency / HBM bound (SURVEY.md section 2 kernel table): f32 VALU math, wave64
+// shuffle reductions, 16-byte coalesced bf16 traffic for V.  No MFMA here on purpose.
+#include "w2c_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- K5: y = act(x W^T + b)
+// One wave per output column o; the wave keeps all M rows' partial sums in registers
+// (MR rows per pass), lanes stride over K four elements at a time.
+template <int MR, bool XBF16>
+__global__ __launch_bounds__(256) void linear_kernel(const void* __restrict__ xv, int x_stride, int M, int K,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     int O, int relu, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= O) return;
+    const float* wrow = w + (size_t)o * K;
+    for (int m0 = 0; m0 < M; m0 += MR) {
+        float acc[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) acc[r] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wrow + k);
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                if (m0 + r < M) {
+                    float x0, x1, x2, x3;
+                    if (XBF16) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(
+                            reinterpret_cast<const uint16_t*>(xv) + (size_t)(m0 + r) * x_stride + k);
+                        x0 = bf16_to_f32((uint16_t)(u.x & 0xFFFFu)); x1 = bf16_to_f32((uint16_t)(u.x >> 16));
+                        x2 = bf16_to_f32((uint16_t)(u.y & 0xFFFFu)); x3 = bf16_to_f32((uint16_t)(u.y >> 16));
+                    } else {
+                        const f32x4_t u = *reinterpret_cast<const f32x4_t*>(
+                            reinterpret_cast<const float*>(xv) + (size_t)(m0 + r) * x_stride + k);
+                        x0 = u[0]; x1 = u[1]; x2 = u[2]; x3 = u[3];
+                    }
+                    acc[r] = fmaf(x0, wv[0], acc[r]);
+                    acc[r] = fmaf(x1, wv[1], acc[r]);
+                    acc[r] = fmaf(x2, wv[2], acc[r]);
+                    acc[r] = fmaf(x3, wv[3], acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0 && m0 + r < M) {
+                float v = s + bias[o];
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)(m0 + r) * O + o] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K6: communication graph
+// score[k][q] = key[k] . (Wq query[q] + bq) = (Wq^T key[k]) . query[q] + key[k] . bq
+// so only T[k] = Wq^T key[k] (Dq values) and t0[k] = key[k].bq are formed: N*Dk*Dq MACs and no
+// [N][Dk] projected-query buffer.
+//   key_project_kernel : one workgroup per (agent k, sample b) row -> T row of Dq+1 floats.
+//                        thread = (column j, K-partition): consecutive lanes read consecutive
+//                        columns of a Wq row (coalesced); partitions reduced through LDS.
+//   comm_graph_kernel  : one workgroup per sample b; one wave per query column, lanes = keys,
+//                        softmax / argmax by wave64 shuffles.  N <= 64.
+constexpr int MAXN = 64;
+
+__global__ __launch_bounds__(256) void key_project_kernel(const float* __restrict__ key, const float* __restrict__ wq,
+                                                          const float* __restrict__ bq, int Dq, int Dk,
+                                                          float* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);          // [parts][Dq]
+    const int row = blockIdx.x;                            // agent-major k*B + b
+    const float* krow = key + (size_t)row * Dk;
+    const int tid = threadIdx.x;
+    const int parts = 256 / Dq;                            // Dq <= 256
+    const int j = tid % Dq, part = tid / Dq;
+    if (part < parts) {
+        float s = 0.f;
+        for (int d = part; d < Dk; d += parts) s = fmaf(wq[(size_t)d * Dq + j], krow[d], s);
+        red[part * Dq + j] = s;
+    }
+    // bias column: every wave takes a strided share, wave 0 finishes
+    float sb = 0.f;
+    for (int d = tid; d < Dk; d += 256) sb = fmaf(bq[d], krow[d], sb);
+    sb = wave_sum(sb);
+    float* redb = red + parts * Dq;
+    if ((tid & 63) == 0) redb[tid >> 6] = sb;
+    __syncthreads();
+    if (tid < Dq) {
+        float s = 0.f;
+        for (int pp = 0; pp < parts; ++pp) s += red[pp * Dq + tid];
+        T[(size_t)row * (Dq + 1) + tid] = s;
+    }
+    if (tid == 0) T[(size_t)row * (Dq + 1) + Dq] = redb[0] + redb[1] + redb[2] + redb[3];
+}
+
+__device__ __forceinline__ void wave_argmax(float& best, int& bidx) {
+    // first maximal index, like torch.argmax / Tensor.max(dim)[1] on CPU
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void comm_graph_kernel(const float* __restrict__ query, const float* __restrict__ T,
+                                                         int B, int N, int Dq, int who, int mode, float thres,
+                                                         float tie_bias, int q_lo, int q_n,
+                                                         float* __restrict__ prob, float* __restrict__ coef,
+                                                         int64_t* __restrict__ action, int32_t* __restrict__ nnz) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    int local_nnz = 0;
+    for (int ql = wave; ql < q_n; ql += 4) {               // one wave per query column
+        const int q = q_lo + ql;
+        const int k = lane;
+        float s = -INFINITY;
+        if (k < N) {
+            const float* trow = T + (size_t)(k * B + b) * (Dq + 1);
+            float d = trow[Dq];
+            if (query) {
+                const float* qrow = query + (size_t)(ql * B + b) * Dq;   // rows of the produced query agents only
+                for (int j = 0; j < Dq; ++j) d = fmaf(trow[j], qrow[j], d);
+            } else {
+                for (int j = 0; j < Dq; ++j) d += trow[j];                 // all-ones query (agent.py:1143,1370)
+            }
+            s = (who && k == q) ? -INFINITY : d;                           // who: diagonal stripped (agent.py:310-318)
+        }
+        const float mx = wave_max(s);
+        const float e = (k < N && s > -INFINITY) ? expf(s - mx) : 0.f;
+        const float den = wave_sum(e);
+        const float p0 = e / den;                                           // softmax over keys (agent.py:274)
+        const float pr = (k < N && !who && k == q) ? p0 + tie_bias : p0;    // prob_action (agent.py:1164-1167)
+        float best = (k < N) ? pr : -INFINITY;
+        int bidx = (k < N) ? k : 0x7fffffff;
+        wave_argmax(best, bidx);
+        float cf;                                                           // coefficient fusing the RETURNED prediction
+        if (mode == 0) cf = p0;                                             // softmax / training (agent.py:1155-1161)
+        else if (mode == 1) cf = (k == bidx) ? 1.f : 0.f;                   // argmax_select (agent.py:1040-1041)
+        else cf = (pr > thres) ? pr : 0.f;                                  // activated_select (agent.py:1062)
+        int act = bidx;
+        if (mode != 0 && !who) {
+            // MIMOcom returns argmax over keys of the connect matrix (agent.py:1189,1200);
+            // MIMOcomWho always argmax(prob_action) (agent.py:1389,1408,1419)
+            float cb = (k < N) ? cf : -INFINITY;
+            int ci = (k < N) ? k : 0x7fffffff;
+            wave_argmax(cb, ci);
+            act = ci;
+        }
+        if (k < N) {
+            const size_t o = ((size_t)b * N + k) * q_n + ql;
+            prob[o] = pr;
+            coef[o] = cf;
+            if (k != q && cf != 0.f) ++local_nnz;
+        }
+        if (lane == 0) action[(size_t)b * q_n + ql] = act;
+    }
+    local_nnz = (int)wave_sum((float)local_nnz);
+    if (lane == 0 && local_nnz) atomicAdd(&cnt, local_nnz);
+    __syncthreads();
+    if (tid == 0) nnz[b] = cnt;
+}
+
+// ---------------------------------------------------------------- K7: fusion
+// thread = 8 channels (16 B) of one (b, pixel); loops queries, skipping zero coefficients
+// (wave-uniform branch: coef depends on (b,k,q) only and a workgroup never spans two b).
+__global__ __launch_bounds__(256) void fuse_kernel(const uint16_t* __restrict__ v, int vcs, const float* __restrict__ coef,
+                                                   int B, int N, int q_lo, int q_n, int hw, int C, int append_own,
+                                                   uint16_t* __restrict__ out, int ocs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cs = reinterpret_cast<float*>(smem);          // [N][q_n] for this b
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < N * q_n; i += 256) cs[i] = coef[(size_t)b * N * q_n + i];
+    __syncthreads();
+    const int CG = C >> 3;
+    const int total = hw * CG;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int px = id / CG, cg = id - px * CG;
+        for (int ql = 0; ql < q_n; ++ql) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int k = 0; k < N; ++k) {
+                const float c = cs[k * q_n + ql];
+                if (c == 0.f) continue;
+                const uint4 u = *reinterpret_cast<const uint4*>(v + ((size_t)(k * B + b) * hw + px) * vcs + cg * 8);
+                const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] = fmaf(c, bf16_to_f32((uint16_t)(wv[e] & 0xFFFFu)), acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(c, bf16_to_f32((uint16_t)(wv[e] >> 16)), acc[2 * e + 1]);
+                }
+            }
+            uint4 o;
+            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+            uint16_t* orow = out + ((size_t)(ql * B + b) * hw + px) * ocs;
+            *reinterpret_cast<uint4*>(orow + cg * 8) = o;
+            if (append_own) {
+                const uint4 own = *reinterpret_cast<const uint4*>(v + ((size_t)((q_lo + ql) * B + b) * hw + px) * vcs + cg * 8);
+                *reinterpret_cast<uint4*>(orow + C + cg * 8) = own;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M, int K,
+                              const float* w, const float* b, int O, int relu, float* y, w2c_stream_t stream) {
+    if (!x || !w || !b || !y || M <= 0 || K <= 0 || O <= 0 || (K % 4) != 0 || (x_stride % 4) != 0) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((O + 3) / 4);
+    if (x_is_bf16)
+        hipLaunchKernelGGL((linear_kernel<16, true>), grid, dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+    else
+        hipLaunchKernelGGL((linear_kernel<16, false>), grid, dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_comm_graph(const float* query, const float* key, const float* wq, const float* bq,
+                              int B, int N, int Dq, int Dk, int who, int mode, float thres, float tie_bias,
+                              int q_lo, int q_n, float* workspace,
+                              float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                              w2c_stream_t stream) {
+    if (!key || !wq || !bq || !workspace || !prob || !coef || !action || !nnz_offdiag) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || Dq > 256 || Dk <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
+    if (q_lo < 0 || q_n <= 0 || q_lo + q_n > N) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)((256 / Dq) * Dq + 4) * 4;
+    hipLaunchKernelGGL(key_project_kernel, dim3(N * B), dim3(256), lds, s, key, wq, bq, Dq, Dk, workspace);
+    hipLaunchKernelGGL(comm_graph_kernel, dim3(B), dim3(256), 0, s, query, workspace, B, N, Dq, who, mode, thres,
+                       tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, int N, int q_lo, int q_n,
+                               int hw, int C, int append_own, uint16_t* out, int out_cstride, w2c_stream_t stream) {
+    if (!v || !coef || !out || B <= 0 || N <= 0 || q_n <= 0 || q_lo < 0 || q_lo + q_n > N) return W2C_E_ARG;
+    if (hw <= 0 || C <= 0 || (C % 8) != 0 || (v_cstride % 8) != 0 || (out_cstride % 8) != 0) return W2C_E_ARG;
+    if (v_cstride < C || out_cstride < (append_own ? 2 * C : C)) return W2C_E_ARG;
+    const int total = hw * (C / 8);
+    int bx = (total + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const size_t lds = (size_t)N * q_n * 4;
+    hipLaunchKernelGGL(fuse_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       v, v_cstride, coef, B, N, q_lo, q_n, hw, C, append_own, out, out_cstride);
+    return w2c_launch_status();
+}

@@ -1,0 +1,206 @@
+// stem.hip -- K1: agent slicing + conv 7x7 stride 2 pad 3 (3 -> 64 per trunk) + BN + ReLU on MFMA,
+// and K1b: maxpool 3x3 s2 p1.
+//
+// Replaces divide_inputs + cat (agent.py:1088-1096,1105-1108) and resnet conv1/bn1/relu/maxpool
+// (backbone.py:65-66,76-80 via the third-party resnet18).  Both trunks (u_encoder and
+// query_key_net.img_encoder) read the same frames, so their stems run side by side as
+// Cout = 128 and the f32 NCHW input is read from HBM exactly once.
+//
+// K = 7*7*3 = 147 is MFMA-unfriendly; it is laid out as 7 (ky) x 8 (kx, tap 7 = zero weight)
+// x 4 (ci, channel 3 = zero) = 224 so that one 16-wide MFMA K-step is two horizontally
+// adjacent input pixels (2 x 4 bf16 = 16 B): the B fragment is ONE aligned ds_read_b128 out of
+// a [row][col][4ch] bf16 input patch in LDS -- no im2col buffer.  Efficiency 147/224 = 66 %.
+//
+// Workgroup = 256 threads, one 8x32 output tile at a time, walking a whole output row band.
+// Wave w owns channel tile (w % (Cout/32)) for 256/PP pixels, and keeps its 32 channels' weights
+// in registers for the whole kernel (14 fragments = 56 VGPRs): LDS holds only the input patch
+// and the bf16 output tile, which is written back as whole 256-B (Cout=128) pixel rows.
+#include "w2c_common.h"
+
+namespace {
+
+constexpr int PATCH_ROWS = 21;     // 2*8 + 5 input rows for 8 output rows
+constexpr int PATCH_COLS = 72;     // 2*32 + 6 (+2 pad) input cols for 32 output cols (+ zero tap)
+constexpr int PATCH_BYTES = PATCH_ROWS * PATCH_COLS * 8;
+
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, int B, int N, int H, int W,
+                                                   const uint16_t* __restrict__ wpk,
+                                                   const float* __restrict__ scale,
+                                                   const float* __restrict__ shift,
+                                                   uint16_t* __restrict__ y) {
+    constexpr int CT = COUT / 32;           // channel tiles
+    constexpr int PP = 4 / CT;              // pixel partitions across waves
+    constexpr int MT = 8 / PP;              // 32-pixel tiles (= output rows) per wave
+    constexpr int ROWBYTES = COUT * 2;      // staged output bytes per pixel
+    constexpr int CHUNKS = ROWBYTES / 16;   // 16-B chunks per pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* patch = reinterpret_cast<uint2*>(smem);
+    char* stagebuf = smem + PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave % CT, pp = wave / CT;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int img = blockIdx.y;                     // agent-major image index a*B + b
+    const int agent = img / B, b = img - agent * B;
+    const int oy0 = blockIdx.x * 8;
+    const float* xin = x + ((size_t)b * 3 * N + 3 * agent) * H * W;   // 3 planes of this agent
+
+    // this wave's weights: A operand, i = channel, k = (kx pair, ci) within one ky
+    bf16x8_t wf[7][2];
+    {
+        const uint16_t* wrow = wpk + (size_t)(ct * 32 + l31) * 224;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[ky][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ky * 32 + (ks * 2 + lhi) * 8);
+    }
+
+    for (int ox0 = 0; ox0 < Wo; ox0 += 32) {
+        // ---- input patch: f32 NCHW planes -> bf16 [row][col][4] in LDS (zero outside the image) ----
+        const int iy_base = 2 * oy0 - 3, ix_base = 2 * ox0 - 3;
+        for (int pidx = tid; pidx < PATCH_ROWS * PATCH_COLS; pidx += 256) {
+            const int r = pidx / PATCH_COLS, c = pidx - r * PATCH_COLS;
+            const int iy = iy_base + r, ix = ix_base + c;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const size_t o = (size_t)iy * W + ix;
+                v0 = xin[o];
+                v1 = xin[o + (size_t)H * W];
+                v2 = xin[o + 2 * (size_t)H * W];
+            }
+            patch[pidx] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f));
+        }
+        __syncthreads();
+
+        f32x16_t acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oyl = pp * MT + mt;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const uint2* prow = patch + (2 * oyl + ky) * PATCH_COLS + 2 * l31 + 2 * lhi;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(prow + ks * 4);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], pb, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: BN scale/shift + ReLU, bf16, stage [pixel][COUT] (chunk-swizzled) ----
+        // D row (channel) = (e&3) + 8*(e>>2) + 4*lhi, D col (pixel) = l31
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = ct * 32 + 8 * q + 4 * lhi;
+            const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + ch);
+            const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(shift + ch);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int px = (pp * MT + mt) * 32 + l31;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[mt][4 * q + r] * sc[r] + sh[r], 0.f);
+                const int chunk = (ct * 4 + q) ^ (px & (CHUNKS - 1));
+                *reinterpret_cast<uint2*>(stagebuf + px * ROWBYTES + chunk * 16 + lhi * 8) =
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+        __syncthreads();
+        // ---- coalesced write-back: 16 B per thread, whole pixel rows ----
+        for (int id = tid; id < 256 * CHUNKS; id += 256) {
+            const int px = id / CHUNKS, cg = id - px * CHUNKS;
+            const uint4 v = *reinterpret_cast<const uint4*>(stagebuf + px * ROWBYTES + ((cg ^ (px & (CHUNKS - 1))) * 16));
+            const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+            *reinterpret_cast<uint4*>(y + (((size_t)img * Ho + oy) * Wo + ox) * COUT + cg * 8) = v;
+        }
+        // next iteration's patch fill is ordered after this iteration's MFMA reads by the
+        // barrier above; its staging writes are ordered after this read-out by the barrier
+        // that follows the patch fill.
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, int M, int H, int W, int C,
+                                                           uint16_t* __restrict__ y) {
+    const int Ho = H >> 1, Wo = W >> 1, CG = C >> 3;
+    const size_t total = (size_t)M * Ho * Wo * CG;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int cg = (int)(id % CG);
+        size_t t = id / CG;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int m = (int)(t / Ho);
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -3.0e38f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= W) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)m * H + iy) * W + ix) * C + cg * 8);
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    best[2 * e] = fmaxf(best[2 * e], bf16_to_f32((uint16_t)(wv[e] & 0xFFFFu)));
+                    best[2 * e + 1] = fmaxf(best[2 * e + 1], bf16_to_f32((uint16_t)(wv[e] >> 16)));
+                }
+            }
+        }
+        uint4 o;
+        o.x = pack_bf16x2(best[0], best[1]); o.y = pack_bf16x2(best[2], best[3]);
+        o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
+        *reinterpret_cast<uint4*>(y + (((size_t)m * Ho + oy) * Wo + ox) * C + cg * 8) = o;
+    }
+}
+
+template <int COUT>
+int launch_stem(const float* x, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+                const float* shift, uint16_t* y, hipStream_t s) {
+    constexpr int lds = PATCH_BYTES + 256 * COUT * 2;
+    static unsigned long long attr_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<COUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_mask |= 1ull << (dev & 63);
+    }
+    dim3 grid((H / 2) / 8, N * B);
+    hipLaunchKernelGGL((stem_kernel<COUT>), grid, dim3(256), lds, s, x, B, N, H, W, w, scale, shift, y);
+    return w2c_launch_status();
+}
+
+}  // namespace
+
+extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int W,
+                                        const uint16_t* w, const float* scale, const float* shift, int Cout,
+                                        uint16_t* y, w2c_stream_t stream) {
+    if (!x || !w || !scale || !shift || !y) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 64) != 0) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (Cout == 128) return launch_stem<128>(x, B, N, H, W, w, scale, shift, y, s);
+    if (Cout == 64) return launch_stem<64>(x, B, N, H, W, w, scale, shift, y, s);
+    return W2C_E_ARG;
+}
+
+extern "C" int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, w2c_stream_t stream) {
+    if (!x || !y || M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8) != 0) return W2C_E_ARG;
+    const size_t total = (size_t)M * (H / 2) * (W / 2) * (C / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;      // grid-stride beyond ~16 workgroups per CU
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, M, H, W, C, y);
+    return w2c_launch_status();
+}

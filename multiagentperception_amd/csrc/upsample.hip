@@ -1,0 +1,128 @@
+// upsample.hip -- K9: bilinear x32 upsample with align_corners=False (simple_decoder,
+// backbone.py:160: F.interpolate(pred, size=(32h, 32w), mode='bilinear', align_corners=False)),
+// plus the two layout converters used at the module boundary / by the parity tests.
+//
+// HBM-write bound: 32*32 f32 outputs per input value (cfg 2: 231 MB written, 0.7 MB read).
+// One workgroup = one (image, class) plane band of 32 output rows; the h x w source plane sits in
+// LDS; every thread produces 4 consecutive x (one 16-B store), so a wave writes 1 KiB runs.
+// Source index math follows ATen's area_pixel_compute_source_index:
+//   src = (dst + 0.5) * (in/out) - 0.5, clamped at 0; i0 = floor(src), i1 = min(i0+1, in-1),
+//   l1 = src - i0, l0 = 1 - l1;  out = l0y*(l0x*p00 + l1x*p01) + l1y*(l0x*p10 + l1x*p11).
+#include "w2c_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
+                                                         float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* plane = reinterpret_cast<float*>(smem);     // [h][w]
+    const int H = h * 32, W = w * 32;
+    const int band = blockIdx.x;                        // 32 output rows
+    const int c = blockIdx.y, m = blockIdx.z;
+    for (int i = threadIdx.x; i < h * w; i += 256) plane[i] = low[((size_t)m * h * w + i) * lcs + c];
+    __syncthreads();
+    const int xq = W >> 2;                              // float4 groups per output row
+    float* obase = out + (((size_t)m * ncls + c) * H + (size_t)band * 32) * W;
+    for (int id = threadIdx.x; id < 32 * xq; id += 256) {
+        const int ry = id / xq, gx = id - ry * xq;
+        const int oy = band * 32 + ry;
+        float sy = (oy + 0.5f) * 0.03125f - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        f32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ox = gx * 4 + e;
+            float sx = (ox + 0.5f) * 0.03125f - 0.5f;
+            sx = sx < 0.f ? 0.f : sx;
+            const int x0 = (int)sx;
+            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            o[e] = ly0 * (lx0 * plane[y0 * w + x0] + lx1 * plane[y0 * w + x1]) +
+                   ly1 * (lx0 * plane[y1 * w + x0] + lx1 * plane[y1 * w + x1]);
+        }
+        *reinterpret_cast<f32x4_t*>(obase + (size_t)ry * W + gx * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int M, int C, int HW,
+                                                           uint16_t* __restrict__ y, int ycs) {
+    const size_t total = (size_t)M * HW * C;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int c = (int)(id % C);
+        const size_t t = id / C;
+        const int p = (int)(t % HW);
+        const int m = (int)(t / HW);
+        y[((size_t)m * HW + p) * ycs + c] = f32_to_bf16(x[((size_t)m * C + c) * HW + p]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const uint16_t* __restrict__ x, int xcs, int M, int C, int HW,
+                                                           float* __restrict__ y) {
+    const size_t total = (size_t)M * HW * C;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int p = (int)(id % HW);
+        const size_t t = id / HW;
+        const int c = (int)(t % C);
+        const int m = (int)(t / C);
+        y[id] = bf16_to_f32(x[((size_t)m * HW + p) * xcs + c]);
+    }
+}
+
+unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
+}
+
+}  // namespace
+
+extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstride, int n_classes,
+                                       float* out, w2c_stream_t stream) {
+    if (!low || !out || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || low_cstride < n_classes) return W2C_E_ARG;
+    if ((size_t)h * w * 4 > 64 * 1024) return W2C_E_ARG;
+    hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), (size_t)h * w * 4,
+                       reinterpret_cast<hipStream_t>(stream), low, h, w, low_cstride, n_classes, out);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_nchw_f32_to_nhwc_bf16(const float* x, int M, int C, int H, int W, uint16_t* y, int y_cstride,
+                                         w2c_stream_t stream) {
+    if (!x || !y || M <= 0 || C <= 0 || H <= 0 || W <= 0 || y_cstride < C) return W2C_E_ARG;
+    const size_t total = (size_t)M * C * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, M, C, H * W, y, y_cstride);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_nhwc_bf16_to_nchw_f32(const uint16_t* x, int x_cstride, int M, int C, int H, int W, float* y,
+                                         w2c_stream_t stream) {
+    if (!x || !y || M <= 0 || C <= 0 || H <= 0 || W <= 0 || x_cstride < C) return W2C_E_ARG;
+    const size_t total = (size_t)M * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, x_cstride, M, C, H * W, y);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_version(void) { return 1; }
+
+extern "C" const char* w2c_status_string(int code) {
+    switch (code) {
+        case W2C_OK: return "ok";
+        case W2C_E_ARG: return "invalid argument or unsupported shape";
+        case W2C_E_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown w2c status";
+    }
+}
+
+extern "C" int w2c_device_arch(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return W2C_E_ARG;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return W2C_E_LAUNCH;
+    int i = 0;
+    for (; i < buflen - 1 && prop.gcnArchName[i]; ++i) buf[i] = prop.gcnArchName[i];
+    buf[i] = 0;
+    return W2C_OK;
+}

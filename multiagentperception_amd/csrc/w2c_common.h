@@ -1,0 +1,42 @@
+// Shared device/host helpers for libw2c_hip.so (gfx950 only; no dual CUDA/HIP paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/w2c_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// global / LDS address-space pointer casts for the LDS-DMA builtin
+#define W2C_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define W2C_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// f32 -> bf16 round-to-nearest-even (finite inputs; activations never NaN by construction,
+// NaN still maps to a NaN pattern because the mantissa carry cannot clear the exponent).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+static inline int w2c_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? W2C_OK : W2C_E_LAUNCH;
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8
+// (MI355X_MICROARCH.md "Workgroup dispatch"), so give every XCD a CONTIGUOUS chunk of tile ids;
+// neighbouring tiles (which share an activation row-panel / a weight column-panel) then hit the
+// same private L2.  Speed only -- correctness never depends on placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + loc;
+}

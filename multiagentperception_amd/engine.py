@@ -1,0 +1,217 @@
+"""HIP engine for the When2com forward path: packs a module's weights once and drives the kernels.
+
+Path (reference file:line -> kernel):
+  divide_inputs + cat + resnet conv1/bn1/relu   agent.py:1088-1108, backbone.py:76-80 -> w2c_stem_conv7x7_bn_relu
+  maxpool                                        backbone.py:66                         -> w2c_maxpool3x3s2
+  layer1..4 BasicBlocks, squeezer, policy convs  backbone.py:66-69, agent.py:54,126-132 -> w2c_conv_igemm_bf16
+  key / query heads                              agent.py:150-159                        -> w2c_linear_f32
+  scores, softmax over keys, mode transforms     agent.py:252-286, 1036-1078, 1164-1167  -> w2c_comm_graph
+  weighted fusion + agents2batch                 agent.py:276-284, 1080-1086             -> w2c_fuse_values
+  decoder convs                                  backbone.py:150-154                     -> w2c_conv_igemm_bf16
+  bilinear x32                                   backbone.py:160                         -> w2c_upsample_bilinear32
+
+HBM layout: bf16 NHWC activations, agent-major images (row = agent*B + sample).  The two
+ResNet-18 trunks of MIMOcom (u_encoder and query_key_net.img_encoder: same shapes, own weights)
+are stored channel-interleaved in one tensor ([.., 2*C]) and executed as 2-group convs from
+the shared stem read up to and including their squeezers; the value map V is channels [0,512)
+of that tensor and the policy net continues from channels [512,1024).
+Eval-mode BatchNorm and conv biases are folded into an f32 per-channel (scale, shift) applied
+to the f32 accumulator (weights are rounded to bf16 unscaled).
+"""
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+BN_EPS_DEFAULT = 1e-5
+
+
+def _fold_bn(bn, conv_bias=None):
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().float() * scale
+    return scale, shift
+
+
+def _pack_w(conv_weight):
+    """[Cout, Cin, kh, kw] f32 -> [Cout, kh*kw*Cin] bf16 (tap-major, channel-minor K)."""
+    w = conv_weight.detach().float()
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(BF16)
+
+
+class ConvPlan:
+    """One w2c_conv_igemm_bf16 call: `groups` same-shape convs side by side."""
+
+    def __init__(self, convs, bns=None, biases=None, relu=True, pad_cout_to=None):
+        c0 = convs[0]
+        self.groups = len(convs)
+        self.cin = c0.in_channels
+        self.cout = c0.out_channels
+        self.ksize = c0.kernel_size[0]
+        self.stride = c0.stride[0]
+        self.relu = relu
+        ws, scs, shs = [], [], []
+        for i, c in enumerate(convs):
+            w = _pack_w(c.weight)
+            if bns is not None:
+                sc, sh = _fold_bn(bns[i], c.bias)
+            else:
+                sc = torch.ones(self.cout, device=w.device)
+                sh = c.bias.detach().float() if c.bias is not None else torch.zeros(self.cout, device=w.device)
+            if pad_cout_to is not None and pad_cout_to > self.cout:
+                extra = pad_cout_to - self.cout
+                w = torch.cat([w, torch.zeros(extra, w.shape[1], dtype=BF16, device=w.device)], 0)
+                sc = torch.cat([sc, torch.ones(extra, device=w.device)])
+                sh = torch.cat([sh, torch.zeros(extra, device=w.device)])
+            ws.append(w)
+            scs.append(sc)
+            shs.append(sh)
+        if pad_cout_to is not None:
+            self.cout = max(self.cout, pad_cout_to)
+        self.w = torch.stack(ws, 0).contiguous()
+        self.scale = torch.cat(scs).contiguous()
+        self.shift = torch.cat(shs).contiguous()
+
+    def run(self, x, x_ch_off=0, residual=None, out_f32=False):
+        return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
+                              self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32)
+
+
+class TrunkPlan:
+    """G ResNet-18 trunks + squeezers run side by side (G = 1 for Single_agent, 2 for MIMOcom*)."""
+
+    def __init__(self, encoders):
+        self.G = len(encoders)
+        fbs = [e.feature_backbone.feature_backbone for e in encoders]
+        # stem: [Cout][7][8][4] bf16, kx==7 / ci==3 zero
+        ws, scs, shs = [], [], []
+        for fb in fbs:
+            w = fb.conv1.weight.detach().float()                       # [64,3,7,7]
+            wp = torch.zeros(64, 7, 8, 4, device=w.device)
+            wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+            ws.append(wp.reshape(64, 224).to(BF16))
+            sc, sh = _fold_bn(fb.bn1)
+            scs.append(sc)
+            shs.append(sh)
+        self.stem_w = torch.cat(ws, 0).contiguous()
+        self.stem_scale = torch.cat(scs).contiguous()
+        self.stem_shift = torch.cat(shs).contiguous()
+        self.blocks = []
+        for li in (1, 2, 3, 4):
+            for bi in (0, 1):
+                blks = [getattr(fb, "layer%d" % li)[bi] for fb in fbs]
+                c1 = ConvPlan([b.conv1 for b in blks], [b.bn1 for b in blks], relu=True)
+                c2 = ConvPlan([b.conv2 for b in blks], [b.bn2 for b in blks], relu=True)      # relu after +identity
+                ds = None
+                if blks[0].downsample is not None:
+                    ds = ConvPlan([b.downsample[0] for b in blks], [b.downsample[1] for b in blks], relu=False)
+                self.blocks.append((c1, c2, ds))
+        sq = [e.squeezer.cbr_unit for e in encoders]
+        self.squeezer = ConvPlan([s[0] for s in sq], [s[1] for s in sq], relu=True)
+
+    def run(self, x, n_agents):
+        """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/32, W/32, G*feat] (squeezer outputs side by side)."""
+        s0 = ops.stem_conv7x7_bn_relu(x, n_agents, self.stem_w, self.stem_scale, self.stem_shift)
+        p = ops.maxpool3x3s2(s0)
+        del s0
+        for c1, c2, ds in self.blocks:
+            t = c1.run(p)
+            idt = p if ds is None else ds.run(p)
+            p = c2.run(t, residual=idt)
+        return self.squeezer.run(p)
+
+
+class HeadPlan:
+    """km_generator / linear: Linear-ReLU-Linear-ReLU-Linear on the NCHW-flattened policy map
+    (agent.py:157-159).  The map arrives NHWC, so fc.0's columns are permuted once instead."""
+
+    def __init__(self, head, hw):
+        fc = head.fc
+        w0 = fc[0].weight.detach().float()
+        n_feat = w0.shape[1]
+        c = n_feat // hw
+        self.w0 = w0.reshape(w0.shape[0], c, hw).permute(0, 2, 1).reshape(w0.shape[0], n_feat).contiguous()
+        self.b0 = fc[0].bias.detach().float().contiguous()
+        self.w1 = fc[2].weight.detach().float().contiguous()
+        self.b1 = fc[2].bias.detach().float().contiguous()
+        self.w2 = fc[4].weight.detach().float().contiguous()
+        self.b2 = fc[4].bias.detach().float().contiguous()
+        self.n_feat = n_feat
+
+    def run(self, qk_map):
+        M = qk_map.shape[0]
+        y = ops.linear(qk_map, self.w0, self.b0, relu=True, x_stride=self.n_feat, rows=M)
+        y = ops.linear(y, self.w1, self.b1, relu=True)
+        return ops.linear(y, self.w2, self.b2, relu=False)
+
+
+class DecoderPlan:
+    def __init__(self, decoder, n_classes):
+        pred = decoder.output_decoder.pred
+        self.c0 = ConvPlan([pred[0]], relu=True)
+        self.c2 = ConvPlan([pred[2]], relu=False, pad_cout_to=32)
+        self.n_classes = n_classes
+
+    def run(self, feat):
+        y = self.c0.run(feat)
+        low = self.c2.run(y, out_f32=True)                  # f32 NHWC [M,h,w,32], channels >= n_classes are 0
+        return ops.upsample_bilinear32(low, self.n_classes), low
+
+
+class CommEngine:
+    """Packed weights + forward for MIMOcom / MIMOcomWho on one device."""
+
+    def __init__(self, model):
+        self.agent_num = model.agent_num
+        self.who = bool(model.attention_net.who)
+        self.has_query = bool(model.has_query)
+        self.n_classes = model.n_classes
+        self.trunk = TrunkPlan([model.u_encoder, model.query_key_net.img_encoder])
+        pn = model.query_key_net
+        self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
+                       for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
+        self.key_head = None        # built lazily: fc.0's column permutation needs the map's h*w
+        self.query_head = None
+        self._model_heads = (model.key_net, model.query_net if self.has_query else None)
+        self.wq = model.attention_net.linear.weight.detach().float().contiguous()
+        self.bq = model.attention_net.linear.bias.detach().float().contiguous()
+        self.decoder = DecoderPlan(model.decoder, self.n_classes)
+        self.feat = 512
+
+    def encode(self, x, n_agents):
+        """-> sq (bf16 NHWC [n*B,h,w,1024]: V in [0,512), policy-encoder map in [512,1024)),
+        keys f32 [n*B,Dk], queries f32 [n*B,Dq] or None."""
+        sq = self.trunk.run(x, n_agents)
+        y = self.policy[0].run(sq, x_ch_off=self.feat)
+        for c in self.policy[1:]:
+            y = c.run(y)
+        hw = y.shape[1] * y.shape[2]
+        if self.key_head is None:
+            self.key_head = HeadPlan(self._model_heads[0], hw)
+            if self._model_heads[1] is not None:
+                self.query_head = HeadPlan(self._model_heads[1], hw)
+        keys = self.key_head.run(y)
+        querys = self.query_head.run(y) if self.query_head is not None else None
+        return sq, keys, querys
+
+    def graph_and_decode(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
+        """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decode."""
+        prob, coef, action, nnz = ops.comm_graph(querys_local, keys_all, self.wq, self.bq, B, N, self.who, mode,
+                                                 q_lo=q_lo, q_n=q_n)
+        fused = ops.fuse_values(sq_all, self.feat, coef, B, N, q_lo, q_n, append_own=self.who)
+        pred, low = self.decoder.run(fused)
+        return pred, prob, action, nnz, low
+
+
+class SingleEngine:
+    def __init__(self, model):
+        self.n_classes = model.n_classes
+        self.trunk = TrunkPlan([model.encoder])
+        self.decoder = DecoderPlan(model.decoder, self.n_classes)
+
+    def forward(self, x):
+        """x f32 [M,3,H,W] -> logits f32 [M,n_classes,H,W] (Single_agent.forward, agent.py:392-395)."""
+        feat = self.trunk.run(x, 1)          # N=1: image index == batch index
+        pred, low = self.decoder.run(feat)
+        return pred, low, feat

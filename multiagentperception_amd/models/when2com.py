@@ -1,0 +1,204 @@
+"""MIMOcom / MIMOcomWho / Single_agent with the reference's constructor arguments, state_dict
+keys, forward signature and return tuple (agent.py:375-395, 983-1204, 1207-1423), running on
+the HIP engine.
+
+Dispatch rule (documented in DESIGN.md): ``module.eval()`` -> the HIP path, always -- it raises
+if the input is not on an MI355X or libw2c_hip.so is missing; there is no CPU/PyTorch fallback
+for it.  ``module.train()`` -> the train-mode path needs batch-statistics BatchNorm and autograd
+(out of the accelerated scope) and runs on stock PyTorch-ROCm ops
+over the same parameters.  Note the reference's ``training`` *argument* is only a return-shape
+flag (validation calls training=True under eval(), trainer.py:692,713); it never selects the path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import engine as _engine
+from .._native import W2CError
+from . import blocks
+
+_INFERENCE_MODES = ("softmax", "argmax_test", "activated")
+
+
+class _EngineCacheMixin:
+    """Packed-weight cache keyed by device, dropped whenever the parameters may have changed
+    (train(), load_state_dict, .to()/.cuda()).  A dict so DataParallel replicas (shallow
+    __dict__ copies, one thread per device) share it safely: one entry per device."""
+
+    def _init_engine_cache(self):
+        self._engines = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._engines.clear())
+
+    def train(self, mode=True):
+        self._engines.clear()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._engines.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _engine_for(self, x, factory):
+        if not x.is_cuda:
+            raise W2CError("%s.forward (eval) runs only on an MI355X device tensor; got input on %s. "
+                           "There is no CPU fallback for the When2com forward path." % (type(self).__name__, x.device))
+        p = next(self.parameters())
+        if p.device != x.device:
+            raise W2CError("input on %s but parameters on %s" % (x.device, p.device))
+        key = (x.device.index if x.device.index is not None else torch.cuda.current_device())
+        eng = self._engines.get(key)
+        if eng is None:
+            with torch.no_grad():
+                eng = factory(self)
+            self._engines[key] = eng
+        return eng
+
+
+class Single_agent(_EngineCacheMixin, nn.Module):
+    def __init__(self, n_classes=21, in_channels=3, feat_channel=512, enc_backbone="resnet_encoder",
+                 dec_backbone="simple_decoder", feat_squeezer=-1):
+        super().__init__()
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.encoder = blocks.img_encoder(n_classes=n_classes, in_channels=in_channels, feat_channel=feat_channel,
+                                          feat_squeezer=feat_squeezer, enc_backbone=enc_backbone)
+        self.decoder = blocks.img_decoder(n_classes=n_classes, in_channels=feat_channel, feat_squeezer=feat_squeezer,
+                                          dec_backbone=dec_backbone)
+        self._init_engine_cache()
+
+    def forward(self, inputs):
+        if self.training:
+            return self.decoder(self.encoder(inputs))                 # stock-op autograd path (see module doc)
+        eng = self._engine_for(inputs, _engine.SingleEngine)
+        with torch.no_grad():
+            pred, _, _ = eng.forward(inputs.contiguous().float())
+        return pred
+
+
+class _MIMOBase(_EngineCacheMixin, nn.Module):
+    _who = False
+
+    def __init__(self, n_classes=21, in_channels=3, feat_channel=512, feat_squeezer=-1, attention="additive",
+                 has_query=True, sparse=False, agent_num=5, shuffle_flag=False, image_size=512,
+                 shared_img_encoder=False, key_size=128, query_size=128, enc_backbone="resnet_encoder",
+                 dec_backbone="simple_decoder"):
+        super().__init__()
+        self.n_classes = n_classes
+        self.agent_num = agent_num
+        self.in_channels = in_channels
+        self.shuffle_flag = shuffle_flag
+        self.feature_map_channel = 512
+        self.key_size = key_size
+        self.query_size = query_size
+        self.shared_img_encoder = shared_img_encoder
+        self.has_query = has_query
+        self.sparse = sparse
+        self.image_size = image_size
+        self._build(n_classes, in_channels, feat_channel, feat_squeezer, image_size, enc_backbone, dec_backbone)
+        # parameter groups the reference exposes (agent.py:1019-1030); unused by its trainers
+        self.attention_paras = list(self.attention_net.parameters())
+        if self.shared_img_encoder == "unified":
+            self.img_net_paras = list(self.u_encoder.parameters()) + list(self.decoder.parameters())
+        self.policy_net_paras = (list(self.query_key_net.parameters()) + list(self.key_net.parameters())
+                                 + self.attention_paras)
+        if self.has_query:
+            self.policy_net_paras = self.policy_net_paras + list(self.query_net.parameters())
+        if self.shared_img_encoder == "unified":
+            self.all_paras = self.img_net_paras + self.policy_net_paras
+        self._init_engine_cache()
+
+    # ---- reference helpers kept for API parity -------------------------------------------
+    def divide_inputs(self, inputs):
+        return [inputs[:, 3 * i:3 * i + 3, :, :] for i in range(self.agent_num)]
+
+    def agents2batch(self, feats):
+        return torch.cat([feats[:, i] for i in range(feats.shape[1])], 0)
+
+    # ---- the hot path ----------------------------------------------------------------------
+    def forward(self, inputs, training=True, MO_flag=False, inference="argmax"):
+        if self.shared_img_encoder != "unified":
+            raise ValueError("Incorrect encoder")                                      # agent.py:1121,1350
+        if self.training:
+            return self._forward_train_stock_ops(inputs, training, MO_flag, inference)
+        if not MO_flag:
+            raise W2CError("MO_flag=False: the reference MIMOcom crashes there (agent.py:1164-1167) and every mrms "
+                           "config sets multiple_output: True; only MO_flag=True is implemented")
+        mode = "softmax" if training else inference
+        if mode not in _INFERENCE_MODES:
+            raise ValueError("Incorrect inference mode")                               # agent.py:1204,1423
+        eng = self._engine_for(inputs, _engine.CommEngine)
+        B, N = inputs.shape[0], self.agent_num
+        with torch.no_grad():
+            x = inputs.contiguous().float()
+            sq, keys, querys = eng.encode(x, N)
+            pred, prob, action, nnz, _ = eng.graph_and_decode(sq, keys, querys, B, N, 0, N, mode)
+        if mode == "softmax":
+            num_connect = self.agent_num - 1                                           # agent.py:1172,1178
+        else:
+            num_connect = int(nnz.sum().item()) / (self.agent_num * B)                 # agent.py:1056,1076
+        return pred, prob, action, num_connect
+
+    # ---- train-mode path: stock PyTorch ops + autograd (outside the accelerated scope) ------
+    def _forward_train_stock_ops(self, inputs, training, MO_flag, inference):
+        if not training:
+            raise W2CError("module is in train() mode but forward(training=False) was requested; call .eval() "
+                           "for inference (the HIP path)")
+        if not MO_flag:
+            raise W2CError("MO_flag=False is not supported (see eval path)")
+        B, N = inputs.shape[0], self.agent_num
+        unified = torch.cat(self.divide_inputs(inputs), 0)
+        feat_maps = self.u_encoder(unified)
+        val_mat = torch.stack([feat_maps[B * i:B * (i + 1)] for i in range(N)], 1)
+        qk = self.query_key_net(unified)
+        keys = self.key_net(qk)
+        key_mat = torch.stack([keys[B * i:B * (i + 1)] for i in range(N)], 1)
+        if self.has_query:
+            qs = self.query_net(qk)
+            query_mat = torch.stack([qs[B * i:B * (i + 1)] for i in range(N)], 1)
+        else:
+            query_mat = torch.ones(B, N, self.query_size, device=inputs.device)
+        scores = torch.bmm(key_mat, self.attention_net.linear(query_mat).transpose(2, 1))
+        if self._who:
+            eye = torch.eye(N, dtype=torch.bool, device=inputs.device).unsqueeze(0)
+            prob = torch.softmax(scores.masked_fill(eye, float("-inf")), dim=1)
+        else:
+            prob = torch.softmax(scores, dim=1)
+        fused = torch.einsum("bkq,bkchw->bqchw", prob, val_mat)
+        if self._who:
+            fused = torch.cat((fused, val_mat), dim=2)
+        pred = self.decoder(self.agents2batch(fused))
+        if not self._who:
+            prob = prob + 0.001 * torch.eye(N, device=inputs.device).unsqueeze(0)
+        return pred, prob, torch.argmax(prob, dim=1), self.agent_num - 1
+
+
+class MIMOcom(_MIMOBase):
+    _who = False
+
+    def _build(self, n_classes, in_channels, feat_channel, feat_squeezer, image_size, enc_backbone, dec_backbone):
+        # registration order follows agent.py:1002-1015
+        self.u_encoder = blocks.img_encoder(n_classes=n_classes, in_channels=in_channels, feat_channel=feat_channel,
+                                            feat_squeezer=feat_squeezer, enc_backbone=enc_backbone)
+        self.key_net = blocks.km_generator(out_size=self.key_size, input_feat_sz=image_size / 32)
+        self.attention_net = blocks.MIMOGeneralDotProductAttention(self.query_size, self.key_size)
+        self.query_key_net = blocks.policy_net4(n_classes=n_classes, in_channels=in_channels, enc_backbone=enc_backbone)
+        if self.has_query:
+            self.query_net = blocks.km_generator(out_size=self.query_size, input_feat_sz=image_size / 32)
+        self.decoder = blocks.img_decoder(n_classes=n_classes, in_channels=self.feature_map_channel,
+                                          feat_squeezer=feat_squeezer, dec_backbone=dec_backbone)
+
+
+class MIMOcomWho(_MIMOBase):
+    _who = True
+
+    def _build(self, n_classes, in_channels, feat_channel, feat_squeezer, image_size, enc_backbone, dec_backbone):
+        # registration order follows agent.py:1226-1243
+        if self.shared_img_encoder != "unified":
+            raise ValueError("Incorrect shared_img_encoder flag")                      # agent.py:1230
+        self.u_encoder = blocks.img_encoder(n_classes=n_classes, in_channels=in_channels, feat_channel=feat_channel,
+                                            feat_squeezer=feat_squeezer, enc_backbone=enc_backbone)
+        self.query_key_net = blocks.policy_net4(n_classes=n_classes, in_channels=in_channels, enc_backbone=enc_backbone)
+        if self.has_query:
+            self.query_net = blocks.linear(out_size=self.query_size, input_feat_sz=image_size / 32)
+        self.key_net = blocks.linear(out_size=self.key_size, input_feat_sz=image_size / 32)
+        self.attention_net = blocks.MIMOWhoGeneralDotProductAttention(self.query_size, self.key_size)
+        self.decoder = blocks.img_decoder(n_classes=n_classes, in_channels=self.feature_map_channel * 2,
+                                          feat_squeezer=feat_squeezer, dec_backbone=dec_backbone)

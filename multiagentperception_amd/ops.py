@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C ABI (include/w2c_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every op below
+hands raw device pointers + sizes to libw2c_hip.so on torch's CURRENT stream of
+the tensor's device (so the path is re-entrant under DataParallel replicas and
+capturable in a graph).  There is no fallback: CPU tensors raise.
+"""
+import torch
+
+from . import _native
+from ._native import W2CError, check
+
+BF16 = torch.bfloat16
+
+
+def _need_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise W2CError("w2c ops run only on an MI355X device tensor (got %s); there is no CPU fallback" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise W2CError("tensors on different devices: %s vs %s" % (dev, t.device))
+        if not t.is_contiguous():
+            raise W2CError("non-contiguous tensor passed to a w2c op")
+    return dev
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+_zero_pages = {}
+
+
+def zero_page(dev):
+    key = (dev.type, dev.index)
+    z = _zero_pages.get(key)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=dev)
+        _zero_pages[key] = z
+    return z
+
+
+def stem_conv7x7_bn_relu(x, n_agents, w_packed, scale, shift, out=None):
+    """x f32 [B,3N,H,W] -> bf16 NHWC [N*B, H/2, W/2, Cout] (agent-major)."""
+    dev = _need_gpu(x, w_packed, scale, shift, out)
+    B, c3n, H, W = x.shape
+    if c3n != 3 * n_agents or x.dtype != torch.float32:
+        raise W2CError("stem: expected f32 [B, 3*%d, H, W], got %s %s" % (n_agents, tuple(x.shape), x.dtype))
+    cout = scale.numel()
+    if out is None:
+        out = torch.empty((n_agents * B, H // 2, W // 2, cout), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_stem_conv7x7_bn_relu(_p(x), B, n_agents, H, W, _p(w_packed), _p(scale), _p(shift),
+                                                     cout, _p(out), _stream(dev)), "w2c_stem_conv7x7_bn_relu")
+    return out
+
+
+def maxpool3x3s2(x, out=None):
+    dev = _need_gpu(x, out)
+    M, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((M, H // 2, W // 2, C), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_maxpool3x3s2(_p(x), M, H, W, C, _p(out), _stream(dev)), "w2c_maxpool3x3s2")
+    return out
+
+
+def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
+               out=None, out_f32=False, out_cstride=None):
+    """x: bf16 NHWC [M,H,W,xcs]; the conv reads channels [x_ch_off + g*cin, ...).  Returns/accepts
+    out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32)."""
+    dev = _need_gpu(x, w_packed, scale, shift, residual, out)
+    M, H, W, xcs = x.shape
+    pad = 1 if ksize == 3 else 0
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    if out_cstride is None:
+        out_cstride = groups * cout
+    if out is None:
+        out = torch.empty((M, Ho, Wo, out_cstride), dtype=torch.float32 if out_f32 else BF16, device=dev)
+    if tuple(out.shape) != (M, Ho, Wo, out_cstride):
+        raise W2CError("conv: bad out shape %s, want %s" % (tuple(out.shape), (M, Ho, Wo, out_cstride)))
+    if residual is not None and tuple(residual.shape) != tuple(out.shape):
+        raise W2CError("conv: residual geometry must equal the output geometry")
+    xptr = x.data_ptr() + 2 * x_ch_off
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
+                                                _p(scale), _p(shift), _p(residual), 1 if relu else 0,
+                                                _p(out), out_cstride, 1 if out_f32 else 0,
+                                                _p(zero_page(dev)), _stream(dev)), "w2c_conv_igemm_bf16")
+    return out
+
+
+def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
+    """y[M,O] = act(x[M,K] W^T + b); x bf16 or f32 (2-D view given by rows/k/x_stride)."""
+    dev = _need_gpu(x, w, b)
+    O, K = w.shape
+    if rows is None:
+        rows = x.shape[0]
+    if x_stride is None:
+        x_stride = K
+    y = torch.empty((rows, O), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_linear_f32(_p(x), 1 if x.dtype == BF16 else 0, x_stride, rows, K, _p(w), _p(b), O,
+                                           1 if relu else 0, _p(y), _stream(dev)), "w2c_linear_f32")
+    return y
+
+
+MODE_IDS = {"softmax": 0, "argmax_test": 1, "activated": 2}
+
+
+def comm_graph(query, key, wq, bq, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None):
+    """-> prob [B,N,q_n] f32, coef [B,N,q_n] f32, action [B,q_n] i64, nnz_offdiag [B] i32."""
+    dev = _need_gpu(query, key, wq, bq)
+    Dk, Dq = wq.shape
+    if q_n is None:
+        q_n = N - q_lo
+    prob = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
+    coef = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
+    action = torch.empty((B, q_n), dtype=torch.int64, device=dev)
+    nnz = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = torch.empty((N * B, Dq + 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_comm_graph(_p(query), _p(key), _p(wq), _p(bq), B, N, Dq, Dk, 1 if who else 0,
+                                           MODE_IDS[mode], float(thres), float(tie_bias), q_lo, q_n, _p(ws),
+                                           _p(prob), _p(coef), _p(action), _p(nnz), _stream(dev)), "w2c_comm_graph")
+    return prob, coef, action, nnz
+
+
+def fuse_values(v, v_ch, coef, B, N, q_lo, q_n, append_own=False, out=None):
+    """v: bf16 NHWC [N*B,h,w,vcs] (first v_ch channels are the value map) -> [q_n*B,h,w,C or 2C]."""
+    dev = _need_gpu(v, coef, out)
+    _, h, w, vcs = v.shape
+    ocs = 2 * v_ch if append_own else v_ch
+    if out is None:
+        out = torch.empty((q_n * B, h, w, ocs), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_fuse_values(_p(v), vcs, _p(coef), B, N, q_lo, q_n, h * w, v_ch, 1 if append_own else 0,
+                                            _p(out), ocs, _stream(dev)), "w2c_fuse_values")
+    return out
+
+
+def upsample_bilinear32(low, n_classes, out=None):
+    """low f32 NHWC [M,h,w,lcs] -> f32 NCHW [M,n_classes,32h,32w]."""
+    dev = _need_gpu(low, out)
+    M, h, w, lcs = low.shape
+    if out is None:
+        out = torch.empty((M, n_classes, 32 * h, 32 * w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_upsample_bilinear32(_p(low), M, h, w, lcs, n_classes, _p(out), _stream(dev)),
+              "w2c_upsample_bilinear32")
+    return out
+
+
+def nchw_f32_to_nhwc_bf16(x, cstride=None):
+    dev = _need_gpu(x)
+    M, C, H, W = x.shape
+    cstride = cstride or C
+    y = torch.zeros((M, H, W, cstride), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_nchw_f32_to_nhwc_bf16(_p(x), M, C, H, W, _p(y), cstride, _stream(dev)),
+              "w2c_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def nhwc_bf16_to_nchw_f32(x, channels=None):
+    dev = _need_gpu(x)
+    M, H, W, cs = x.shape
+    C = channels or cs
+    y = torch.empty((M, C, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_nhwc_bf16_to_nchw_f32(_p(x), cs, M, C, H, W, _p(y), _stream(dev)),
+              "w2c_nhwc_bf16_to_nchw_f32")
+    return y

@@ -1,0 +1,276 @@
+"""GPU parity, kernel by kernel, THROUGH the C ABI (multiagentperception_amd.ops -> libw2c_hip.so).
+
+Each kernel is compared with an fp32 torch-CPU evaluation of the reference op on the SAME
+bf16-representable inputs, so the only differences are accumulation order and the final
+rounding; tolerances are stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import when2com_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _bf16r(t):
+    """round an f32 tensor to bf16-representable values (still f32)."""
+    return t.to(BF16).float()
+
+
+def _rand(gen, *shape, scale=1.0):
+    return _bf16r(torch.randn(*shape, generator=gen) * scale)
+
+
+def _nhwc(x_nchw, cstride=None, ch_off=0):
+    """f32 NCHW (CPU) -> bf16 NHWC on device with optional wider channel stride."""
+    m, c, h, w = x_nchw.shape
+    cs = cstride or c
+    buf = torch.zeros(m, h, w, cs, dtype=BF16)
+    buf[..., ch_off:ch_off + c] = x_nchw.permute(0, 2, 3, 1).to(BF16)
+    return buf.to(_dev())
+
+
+def _to_nchw(y_nhwc, ch_off=0, c=None):
+    y = y_nhwc.float().cpu()
+    c = c or y.shape[-1]
+    return y[..., ch_off:ch_off + c].permute(0, 3, 1, 2).contiguous()
+
+
+def test_library_loaded_and_arch():
+    from multiagentperception_amd import _native
+    import ctypes
+    lib = _native.lib()
+    assert lib.w2c_version() >= 1
+    buf = ctypes.create_string_buffer(64)
+    torch.zeros(1, device=_dev())
+    assert lib.w2c_device_arch(buf, 64) == 0
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+CONV_CASES = [
+    # M, H, W, Cin, Cout, ks, stride, groups, residual, relu, f32out   -> tile variant exercised
+    (2, 16, 16, 64, 64, 3, 1, 1, False, True, True),       # 64x64 tile
+    (2, 16, 16, 64, 64, 3, 1, 2, True, True, False),       # 2 groups + residual, bf16 out
+    (1, 12, 20, 64, 128, 3, 2, 2, False, True, True),      # stride 2, non-square, 2 groups
+    (3, 9, 7, 128, 128, 1, 2, 1, False, False, True),      # 1x1 s2 downsample, ragged rows (3*5*4=60)
+    (3, 5, 5, 64, 64, 3, 1, 1, True, True, True),          # rows=75: ragged last tile
+    (1, 8, 8, 256, 32, 3, 1, 1, False, False, True),       # Cout=32 (padded decoder head) 128x32 tile
+    (2, 128, 128, 64, 256, 3, 1, 1, False, True, False),   # rows=32768, Cout 256 -> 128x128 tile
+    (4, 64, 64, 64, 64, 3, 1, 2, True, True, False),       # rows=16384 x2 groups -> 128x64 tile
+    (2, 4, 4, 512, 512, 3, 1, 1, False, True, True),       # deep K (72 K-steps), tiny M
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_igemm_matches_fp32_conv(case):
+    from multiagentperception_amd import ops
+    M, H, W, cin, cout, ks, stride, G, use_res, relu, f32out = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    pad = 1 if ks == 3 else 0
+    xs = [_rand(gen, M, cin, H, W) for _ in range(G)]
+    ws = [_rand(gen, cout, cin, ks, ks, scale=(2.0 / (cin * ks * ks)) ** 0.5) for _ in range(G)]
+    scale = torch.rand(G * cout, generator=gen) + 0.5
+    shift = torch.randn(G * cout, generator=gen) * 0.1
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    ress = [_rand(gen, M, cout, Ho, Wo) for _ in range(G)] if use_res else None
+
+    x_dev = torch.zeros(M, H, W, G * cin, dtype=BF16)
+    for g in range(G):
+        x_dev[..., g * cin:(g + 1) * cin] = xs[g].permute(0, 2, 3, 1).to(BF16)
+    x_dev = x_dev.to(_dev())
+    w_dev = torch.stack([w.permute(0, 2, 3, 1).reshape(cout, -1).to(BF16) for w in ws], 0).contiguous().to(_dev())
+    res_dev = None
+    if use_res:
+        res_dev = torch.zeros(M, Ho, Wo, G * cout, dtype=BF16)
+        for g in range(G):
+            res_dev[..., g * cout:(g + 1) * cout] = ress[g].permute(0, 2, 3, 1).to(BF16)
+        res_dev = res_dev.to(_dev())
+    y = ops.conv_igemm(x_dev, 0, cin, w_dev, cout, ks, stride, G, scale.to(_dev()), shift.to(_dev()),
+                       residual=res_dev, relu=relu, out_f32=f32out)
+    torch.cuda.synchronize()
+    for g in range(G):
+        ref = F.conv2d(xs[g], ws[g], None, stride=stride, padding=pad)
+        ref = ref * scale[g * cout:(g + 1) * cout].view(1, -1, 1, 1) + shift[g * cout:(g + 1) * cout].view(1, -1, 1, 1)
+        if use_res:
+            ref = ref + ress[g]
+        if relu:
+            ref = F.relu(ref)
+        got = _to_nchw(y, g * cout, cout)
+        # f32 out: only accumulation order differs (K <= 4608 terms of O(1/sqrt(K))): 2e-4 abs.
+        # bf16 out: plus one bf16 rounding of the result: 2^-8 relative.
+        if f32out:
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-4, rtol=2e-4)
+        else:
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("cout,B,N,H,W", [(64, 2, 1, 64, 64), (128, 2, 3, 64, 128), (128, 1, 2, 128, 128)])
+def test_stem_matches_fp32_conv7x7_bn_relu(cout, B, N, H, W):
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(cout + B + N)
+    x = torch.rand(B, 3 * N, H, W, generator=gen) - 0.45           # AirSim-ranged f32 (NOT bf16-rounded: kernel rounds)
+    G = cout // 64
+    ws = [_rand(gen, 64, 3, 7, 7, scale=(2.0 / 147) ** 0.5) for _ in range(G)]
+    scale = torch.rand(cout, generator=gen) + 0.5
+    shift = torch.randn(cout, generator=gen) * 0.1
+    wp = torch.zeros(cout, 7, 8, 4)
+    for g in range(G):
+        wp[g * 64:(g + 1) * 64, :, :7, :3] = ws[g].permute(0, 2, 3, 1)
+    y = ops.stem_conv7x7_bn_relu(x.to(_dev()), N, wp.reshape(cout, 224).to(BF16).to(_dev()), scale.to(_dev()),
+                                 shift.to(_dev()))
+    torch.cuda.synchronize()
+    unified = orc.unify_inputs(_bf16r(x), N)                        # agent-major [N*B,3,H,W]
+    for g in range(G):
+        ref = F.conv2d(unified, ws[g], None, stride=2, padding=3)
+        ref = F.relu(ref * scale[g * 64:(g + 1) * 64].view(1, -1, 1, 1) + shift[g * 64:(g + 1) * 64].view(1, -1, 1, 1))
+        got = _to_nchw(y, g * 64, 64)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)   # bf16 output rounding
+
+
+def test_maxpool_is_exact():
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    x = _rand(gen, 3, 16, 10, 12)
+    y = ops.maxpool3x3s2(_nhwc(x))
+    torch.cuda.synchronize()
+    ref = F.max_pool2d(x, 3, 2, 1)
+    np.testing.assert_array_equal(_to_nchw(y).numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("M,K,O,bf16_in,relu", [(20, 4096, 256, True, True), (20, 256, 128, False, True),
+                                                (10, 128, 1024, False, False), (33, 256, 32, False, False),
+                                                (1, 16384, 256, True, True)])
+def test_linear_matches_fp32(M, K, O, bf16_in, relu):
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(M + K + O)
+    x = torch.randn(M, K, generator=gen)
+    if bf16_in:
+        x = _bf16r(x)
+    w = torch.randn(O, K, generator=gen) / K ** 0.5
+    b = torch.randn(O, generator=gen) * 0.1
+    xd = x.to(BF16).to(_dev()) if bf16_in else x.to(_dev())
+    y = ops.linear(xd, w.to(_dev()), b.to(_dev()), relu)
+    torch.cuda.synchronize()
+    ref = F.linear(x, w, b)
+    if relu:
+        ref = F.relu(ref)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)   # f32 both sides, sum order only
+
+
+def _ref_graph(query, key, wq, bq, B, N, who, mode):
+    sd = {"attention_net.linear.weight": wq, "attention_net.linear.bias": bq}
+    qm = orc._regroup(query, B, N) if query is not None else torch.ones(B, N, wq.shape[1])
+    km = orc._regroup(key, B, N)
+    s = orc.attention_scores(qm, km, sd)
+    if who:
+        s = s.masked_fill(torch.eye(N, dtype=torch.bool).unsqueeze(0), float("-inf"))
+    p0 = torch.softmax(s, dim=1)
+    prob = p0 if who else p0 + 0.001 * torch.eye(N).unsqueeze(0)
+    if mode == "softmax":
+        coef = p0
+    elif mode == "argmax_test":
+        coef = F.one_hot(prob.max(dim=1)[1], num_classes=N).float().transpose(1, 2)
+    else:
+        coef = prob * (prob > 0.2).float()
+    action = torch.argmax(prob, dim=1) if (who or mode == "softmax") else torch.argmax(coef, dim=1)
+    nnz = torch.stack([(c * (1 - torch.eye(N)) != 0).sum() for c in coef])
+    return prob, coef, action, nnz
+
+
+@pytest.mark.parametrize("who", [False, True])
+@pytest.mark.parametrize("mode", ["softmax", "argmax_test", "activated"])
+@pytest.mark.parametrize("B,N,has_q", [(4, 5, True), (2, 2, True), (1, 16, True), (3, 6, False), (1, 40, True)])
+def test_comm_graph_matches_reference_attention(who, mode, B, N, has_q):
+    from multiagentperception_amd import ops
+    Dq, Dk = 32, 1024
+    gen = torch.Generator().manual_seed(B * 100 + N + (7 if who else 0))
+    key = torch.randn(N * B, Dk, generator=gen) * 0.3
+    query = torch.randn(N * B, Dq, generator=gen) if has_q else None
+    wq = torch.randn(Dk, Dq, generator=gen) / Dq ** 0.5 * 0.5
+    bq = torch.randn(Dk, generator=gen) * 0.05
+    prob, coef, action, nnz = ops.comm_graph(None if query is None else query.to(_dev()), key.to(_dev()),
+                                             wq.to(_dev()), bq.to(_dev()), B, N, who, mode)
+    torch.cuda.synchronize()
+    rp, rc, ra, rn = _ref_graph(query, key, wq, bq, B, N, who, mode)
+    np.testing.assert_allclose(prob.cpu().numpy(), rp.numpy(), atol=2e-6)       # f32, re-associated score sum
+    # threshold / argmax decisions can only differ where the reference itself is within 1e-5 of a tie
+    stable = (rp - 0.2).abs().min() > 1e-5
+    top2 = rp.topk(2, dim=1)[0] if N > 1 else None
+    stable = stable and (top2 is None or (top2[:, 0] - top2[:, 1]).min() > 1e-5)
+    if stable:
+        np.testing.assert_allclose(coef.cpu().numpy(), rc.numpy(), atol=2e-6)
+        np.testing.assert_array_equal(action.cpu().numpy(), ra.numpy())
+        np.testing.assert_array_equal(nnz.cpu().numpy(), rn.numpy())
+
+
+def test_comm_graph_query_slice_equals_full():
+    """agent-parallel ranks ask for a slice of the query agents; columns must equal the full call."""
+    from multiagentperception_amd import ops
+    B, N, Dq, Dk = 2, 6, 32, 1024
+    gen = torch.Generator().manual_seed(3)
+    key = (torch.randn(N * B, Dk, generator=gen) * 0.3).to(_dev())
+    query = torch.randn(N * B, Dq, generator=gen).to(_dev())
+    wq = (torch.randn(Dk, Dq, generator=gen) * 0.1).to(_dev())
+    bq = (torch.randn(Dk, generator=gen) * 0.05).to(_dev())
+    full = ops.comm_graph(query, key, wq, bq, B, N, False, "activated")
+    for lo, n in ((0, 2), (2, 3), (5, 1)):
+        part = ops.comm_graph(query[lo * B:(lo + n) * B].contiguous(), key, wq, bq, B, N, False, "activated", q_lo=lo, q_n=n)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(part[0].cpu().numpy(), full[0][:, :, lo:lo + n].cpu().numpy())
+        np.testing.assert_array_equal(part[1].cpu().numpy(), full[1][:, :, lo:lo + n].cpu().numpy())
+        np.testing.assert_array_equal(part[2].cpu().numpy(), full[2][:, lo:lo + n].cpu().numpy())
+
+
+@pytest.mark.parametrize("B,N,append_own,sparse", [(4, 5, False, False), (2, 3, True, False), (2, 6, False, True)])
+def test_fuse_values_matches_einsum(B, N, append_own, sparse):
+    from multiagentperception_amd import ops
+    C, h, w = 512, 4, 4
+    gen = torch.Generator().manual_seed(B + N)
+    v = _rand(gen, N * B, C, h, w)
+    coef = torch.softmax(torch.randn(B, N, N, generator=gen) * 2, dim=1)
+    if sparse:
+        coef = coef * (coef > 0.2).float()
+    vd = _nhwc(v, cstride=2 * C)                     # V lives in channels [0,512) of a 1024-wide tensor
+    out = ops.fuse_values(vd, C, coef.to(_dev()), B, N, 0, N, append_own=append_own)
+    torch.cuda.synchronize()
+    vm = orc._regroup(v, B, N)
+    ref = orc.agents2batch(orc.fuse(coef, vm))
+    got = _to_nchw(out, 0, C)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-3, rtol=2 ** -7)    # bf16 rounding of the sum
+    if append_own:
+        np.testing.assert_array_equal(_to_nchw(out, C, C).numpy(), v.numpy())
+
+
+@pytest.mark.parametrize("M,h,w", [(3, 4, 4), (2, 16, 16), (1, 8, 5)])
+def test_upsample_matches_interpolate(M, h, w):
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(M + h)
+    low = torch.randn(M, 11, h, w, generator=gen)
+    lowd = torch.zeros(M, h, w, 32)
+    lowd[..., :11] = low.permute(0, 2, 3, 1)
+    out = ops.upsample_bilinear32(lowd.to(_dev()), 11)
+    torch.cuda.synchronize()
+    ref = F.interpolate(low, size=(32 * h, 32 * w), mode="bilinear", align_corners=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-6, rtol=1e-6)
+
+
+def test_bad_arguments_raise_not_abort():
+    from multiagentperception_amd import ops
+    from multiagentperception_amd._native import W2CError
+    with pytest.raises(W2CError):
+        ops.maxpool3x3s2(torch.zeros(1, 4, 4, 8, dtype=BF16))                 # CPU tensor: no fallback
+    x = torch.zeros(1, 8, 8, 48, dtype=BF16, device=_dev())
+    w = torch.zeros(1, 64, 9 * 48, dtype=BF16, device=_dev())
+    s = torch.ones(64, device=_dev())
+    with pytest.raises(W2CError):
+        ops.conv_igemm(x, 0, 48, w, 64, 3, 1, 1, s, s)                        # Cin % 64 != 0
