@@ -37,6 +37,8 @@ typedef void* w2c_stream_t;
 
 int w2c_version(void);
 const char* w2c_status_string(int code);
+/* HIP error name + text of the calling thread's last W2C_E_LAUNCH (empty string if none) */
+const char* w2c_last_error_string(void);
 /* name of the device the calling thread is on, gcnArchName (e.g. "gfx950:...") */
 int w2c_device_arch(char* buf, int buflen);
 

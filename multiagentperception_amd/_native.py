@@ -18,6 +18,7 @@ _vp, _i, _f = _c.c_void_p, _c.c_int, _c.c_float
 SIGNATURES = {
     "w2c_version": [],
     "w2c_status_string": [_i],
+    "w2c_last_error_string": [],
     "w2c_device_arch": [_c.c_char_p, _i],
     "w2c_stem_conv7x7_bn_relu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "w2c_maxpool3x3s2": [_vp, _i, _i, _i, _i, _vp, _vp],
@@ -40,6 +41,11 @@ class W2CError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        # torch wheels bundle their own libamdhip64.so; load torch FIRST so that our library's
+        # NEEDED libamdhip64.so.7 resolves to that already-loaded runtime.  Loading ours first
+        # pulls /opt/rocm's copy in as a second HIP runtime and every launch then fails with
+        # hipErrorNoDevice.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise W2CError(
                 "libw2c_hip.so not found at %s -- build it with "
@@ -52,7 +58,7 @@ def lib():
             except AttributeError:
                 raise W2CError("libw2c_hip.so does not export %s (stale build?)" % name)
             fn.argtypes = argtypes
-            fn.restype = _c.c_char_p if name == "w2c_status_string" else _i
+            fn.restype = _c.c_char_p if name in ("w2c_status_string", "w2c_last_error_string") else _i
         _lib = handle
     return _lib
 
@@ -60,4 +66,6 @@ def lib():
 def check(code, what):
     if code != 0:
         msg = lib().w2c_status_string(code)
-        raise W2CError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))
+        detail = lib().w2c_last_error_string() if code == -2 else b""
+        raise W2CError("%s failed: %s (code %d) %s" % (what, msg.decode() if msg else "?", code,
+                                                      detail.decode() if detail else ""))

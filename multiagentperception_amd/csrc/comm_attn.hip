@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(const uint16_t* __restrict__ 
 
 extern "C" int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M, int K,
                               const float* w, const float* b, int O, int relu, float* y, w2c_stream_t stream) {
+    w2c_clear_error();
     if (!x || !w || !b || !y || M <= 0 || K <= 0 || O <= 0 || (K % 4) != 0 || (x_stride % 4) != 0) return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((O + 3) / 4);
@@ -249,6 +250,7 @@ extern "C" int w2c_comm_graph(const float* query, const float* key, const float*
                               int q_lo, int q_n, float* workspace,
                               float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
                               w2c_stream_t stream) {
+    w2c_clear_error();
     if (!key || !wq || !bq || !workspace || !prob || !coef || !action || !nnz_offdiag) return W2C_E_ARG;
     if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || Dq > 256 || Dk <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
     if (q_lo < 0 || q_n <= 0 || q_lo + q_n > N) return W2C_E_ARG;
@@ -262,6 +264,7 @@ extern "C" int w2c_comm_graph(const float* query, const float* key, const float*
 
 extern "C" int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, int N, int q_lo, int q_n,
                                int hw, int C, int append_own, uint16_t* out, int out_cstride, w2c_stream_t stream) {
+    w2c_clear_error();
     if (!v || !coef || !out || B <= 0 || N <= 0 || q_n <= 0 || q_lo < 0 || q_lo + q_n > N) return W2C_E_ARG;
     if (hw <= 0 || C <= 0 || (C % 8) != 0 || (v_cstride % 8) != 0 || (out_cstride % 8) != 0) return W2C_E_ARG;
     if (v_cstride < C || out_cstride < (append_own ? 2 * C : C)) return W2C_E_ARG;

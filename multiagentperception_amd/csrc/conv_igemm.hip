@@ -272,6 +272,7 @@ extern "C" int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int C
                                    const uint16_t* residual, int relu,
                                    void* y, int y_cstride, int y_is_f32,
                                    const void* zero_page, w2c_stream_t stream) {
+    w2c_clear_error();
     if (!x || !w || !scale || !shift || !y || !zero_page) return W2C_E_ARG;
     if (M <= 0 || H <= 0 || W <= 0 || groups <= 0) return W2C_E_ARG;
     if (Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 32) != 0) return W2C_E_ARG;

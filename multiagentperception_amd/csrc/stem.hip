@@ -187,6 +187,7 @@ int launch_stem(const float* x, int B, int N, int H, int W, const uint16_t* w, c
 extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int W,
                                         const uint16_t* w, const float* scale, const float* shift, int Cout,
                                         uint16_t* y, w2c_stream_t stream) {
+    w2c_clear_error();
     if (!x || !w || !scale || !shift || !y) return W2C_E_ARG;
     if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 64) != 0) return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -196,6 +197,7 @@ extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int
 }
 
 extern "C" int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, w2c_stream_t stream) {
+    w2c_clear_error();
     if (!x || !y || M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8) != 0) return W2C_E_ARG;
     const size_t total = (size_t)M * (H / 2) * (W / 2) * (C / 8);
     size_t blocks = (total + 255) / 256;

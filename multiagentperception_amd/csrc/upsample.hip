@@ -80,6 +80,7 @@ unsigned grid_for(size_t total) {
 
 extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                                        float* out, w2c_stream_t stream) {
+    w2c_clear_error();
     if (!low || !out || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || low_cstride < n_classes) return W2C_E_ARG;
     if ((size_t)h * w * 4 > 64 * 1024) return W2C_E_ARG;
     hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), (size_t)h * w * 4,
@@ -89,6 +90,7 @@ extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, in
 
 extern "C" int w2c_nchw_f32_to_nhwc_bf16(const float* x, int M, int C, int H, int W, uint16_t* y, int y_cstride,
                                          w2c_stream_t stream) {
+    w2c_clear_error();
     if (!x || !y || M <= 0 || C <= 0 || H <= 0 || W <= 0 || y_cstride < C) return W2C_E_ARG;
     const size_t total = (size_t)M * C * H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -98,6 +100,7 @@ extern "C" int w2c_nchw_f32_to_nhwc_bf16(const float* x, int M, int C, int H, in
 
 extern "C" int w2c_nhwc_bf16_to_nchw_f32(const uint16_t* x, int x_cstride, int M, int C, int H, int W, float* y,
                                          w2c_stream_t stream) {
+    w2c_clear_error();
     if (!x || !y || M <= 0 || C <= 0 || H <= 0 || W <= 0 || x_cstride < C) return W2C_E_ARG;
     const size_t total = (size_t)M * C * H * W;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -106,6 +109,8 @@ extern "C" int w2c_nhwc_bf16_to_nchw_f32(const uint16_t* x, int x_cstride, int M
 }
 
 extern "C" int w2c_version(void) { return 1; }
+
+extern "C" const char* w2c_last_error_string(void) { return w2c_errbuf(); }
 
 extern "C" const char* w2c_status_string(int code) {
     switch (code) {

@@ -25,9 +25,26 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// Last HIP error text of the calling thread (for w2c_last_error_string()).
+inline char* w2c_errbuf() {
+    static thread_local char buf[256] = {0};
+    return buf;
+}
+// Clear any stale (non-sticky) HIP error left by an earlier caller in this thread, so that the
+// status we return belongs to OUR launch.
+static inline void w2c_clear_error() { (void)hipGetLastError(); }
 static inline int w2c_launch_status() {
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? W2C_OK : W2C_E_LAUNCH;
+    if (e == hipSuccess) return W2C_OK;
+    char* b = w2c_errbuf();
+    const char* n = hipGetErrorName(e);
+    const char* m = hipGetErrorString(e);
+    int i = 0;
+    for (const char* p = n; p && *p && i < 100; ++p) b[i++] = *p;
+    b[i++] = ':'; b[i++] = ' ';
+    for (const char* p = m; p && *p && i < 250; ++p) b[i++] = *p;
+    b[i] = 0;
+    return W2C_E_LAUNCH;
 }
 
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8

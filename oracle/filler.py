@@ -62,15 +62,14 @@ def canonical_name(name):
 
 def _gain(name):
     """Per-tensor gain overrides (everything else is He/Glorot-like)."""
-    # heads + attention projection: make softmax_k(key . W q) peaked but not
-    # saturated (score spread of a few units) so 'activated' (P > 0.2,
-    # agent.py:1060-1062) is not a knife-edge on every entry.
-    if name.endswith("key_net.fc.4.weight"):
-        return 3.0
+    # query head + attention projection: a 3x total gain makes softmax_k(key . W q)
+    # peaked (max P ~0.5-0.9) while keeping |score| ~10, so that 'activated'
+    # (P > 0.2, agent.py:1060-1062) is not a knife-edge on every entry AND the
+    # fixture does not amplify bf16 rounding of the keys (delta_score ~ 6e-3 * |score|).
     if name.endswith("query_net.fc.4.weight"):
-        return 3.0
+        return 1.5
     if name.endswith("attention_net.linear.weight"):
-        return 3.0
+        return 2.0
     # second BN of every BasicBlock: damp the residual branch so the trunk's
     # variance does not double per block with eval-mode (non-normalising) BN.
     if ".bn2.weight" in name:
@@ -130,13 +129,20 @@ def synthetic_frames(batch, agents, height, width, seed):
     yy = np.arange(height, dtype=np.float64)[:, None] / height
     xx = np.arange(width, dtype=np.float64)[None, :] / width
     ph = uniform_pm1("phase", batch * agents * 3 * 4, salt=seed).reshape(batch, agents, 3, 4)
+    # per-(sample, agent) brightness / contrast / noise level: agents see DIFFERENT scenes, so
+    # their keys differ by more than a common-mode component (as real multi-view frames do).
+    st = uniform_pm1("style", batch * agents * 3, salt=seed).reshape(batch, agents, 3)
+
     # triangle waves, not sin/cos: only IEEE add/mul/floor, so the u8 image is
     # bit-identical on every host (no libm last-ulp differences).
     def tri(t):
         return 1.0 - 4.0 * np.abs(t - np.floor(t) - 0.5)
     field = (tri(yy * (1.0 + ph[..., 0, None, None] * 2) + ph[..., 1, None, None])
              * tri(xx * (1.0 + ph[..., 2, None, None] * 2) + ph[..., 3, None, None]))
-    u8 = np.clip(np.floor(127.5 + 80.0 * field + 47.0 * noise), 0, 255)
+    off = 127.5 + 70.0 * st[..., 0, None, None, None]
+    amp = 50.0 + 40.0 * st[..., 1, None, None, None]
+    nz = 25.0 + 20.0 * st[..., 2, None, None, None]
+    u8 = np.clip(np.floor(off + amp * field + nz * noise), 0, 255)
     mean = np.array([103.939, 116.779, 123.68], dtype=np.float64)[None, None, :, None, None]
     img = ((u8 - mean) / 255.0).astype(np.float32)
     return img.reshape(batch, agents * 3, height, width)

@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 from oracle import filler  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+MARGIN = 0.04
 
 
 # ---- stub of the un-vendored third-party resnet18 (torchvision layout) ----
@@ -172,7 +173,19 @@ def run_case(ref_models, ref_metrics, name, arch, yml, agent_num, batch, size, m
         rs.update(labels, pred.max(1)[1].numpy())
         out["miou"] = np.float64(rs.get_scores()[0]["Mean IoU : \t"])
     else:
-        x = torch.from_numpy(filler.synthetic_frames(batch, agent_num, size, size, seed))
+        # 'activated' thresholds P at 0.2 (agent.py:1060-1062): pick the first seed >= the nominal
+        # one whose reference P stays >= MARGIN away from the threshold and whose per-query top-2
+        # gap is >= MARGIN, so a bf16 pipeline cannot flip a coefficient / an argmax on 1 ulp.
+        for seed in range(seed, seed + 400):
+            x = torch.from_numpy(filler.synthetic_frames(batch, agent_num, size, size, seed))
+            with torch.no_grad():
+                _, p_try, _, _ = model(x, training=False, MO_flag=True, inference="softmax")
+            top2 = p_try.topk(2, dim=1)[0]
+            if float((p_try - 0.2).abs().min()) >= MARGIN and float((top2[:, 0] - top2[:, 1]).min()) >= MARGIN:
+                break
+        else:
+            raise RuntimeError("no seed with margin for " + name)
+        meta["seed"] = seed
         labels = filler.synthetic_labels(batch * agent_num, size, size, seed)
         for mode in modes:
             grabbed, hs = capture_intermediates(model, arch)
@@ -200,6 +213,8 @@ def run_case(ref_models, ref_metrics, name, arch, yml, agent_num, batch, size, m
         # knife-edge guard for 'activated' (agent.py:1060-1062): refuse fixtures within 5e-3 of 0.2
         p = out[modes[0] + "_prob"]
         meta["min_dist_to_thres"] = float(np.abs(p - 0.2).min())
+        t2 = np.sort(p, axis=1)[:, -2:, :]
+        meta["min_top2_gap"] = float((t2[:, 1] - t2[:, 0]).min())
         meta["prob_max_mean"] = float(p.max(axis=1).mean())
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     return meta, spec

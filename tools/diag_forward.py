@@ -1,0 +1,86 @@
+"""Diagnostic (not a test): stage-by-stage error of the HIP path vs the fp32 oracle, next to a CPU
+emulation of bf16 storage rounding (what ANY bf16 pipeline would lose on these weights)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import filler  # noqa
+from oracle import when2com_oracle as orc  # noqa
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def emulated(sd, x, n, has_query=True):
+    """oracle with conv inputs/weights and every ReLU output rounded to bf16."""
+    real_conv, real_relu = F.conv2d, F.relu
+    try:
+        orc.F.conv2d = lambda inp, w, b=None, **k: real_conv(bf16r(inp), bf16r(w), b, **k)
+        orc.F.relu = lambda t, *a, **k: bf16r(real_relu(t))
+        ex = {}
+        out = orc.mimocom_forward(sd, x, n, training=False, MO_flag=True, inference="softmax", has_query=has_query, extras=ex)
+    finally:
+        orc.F.conv2d, orc.F.relu = real_conv, real_relu
+    return out, ex
+
+
+def main():
+    B, N, S, seed = 2, 5, 128, 11
+    if len(sys.argv) > 1:
+        B, N, S, seed = [int(v) for v in sys.argv[1:5]]
+    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
+    sd = orc.to_torch(filler.fill_state_dict(orc.state_spec("MIMOcom", image_size=S)))
+    ex = {}
+    rpred, rprob, _, _ = orc.mimocom_forward(sd, x, N, training=False, MO_flag=True, inference="softmax", extras=ex)
+    (epred, eprob, _, _), eex = emulated(sd, x, N)
+    print("oracle stats: V std %.3f  keys std %.3f  query std %.3f  logits std %.4f" % (
+        ex["val_mat"].std(), ex["key_mat"].std(), ex["query_mat"].std(), rpred.std()))
+    s_ref = orc.attention_scores(ex["query_mat"], ex["key_mat"], sd)
+    print("scores: std over keys %.3f  abs max %.3f" % (s_ref.std(dim=1).mean(), s_ref.abs().max()))
+    print("[emulated bf16 on CPU]  V rel %.2e  keys rel %.2e  query rel %.2e  P maxabs %.2e  logits rel %.2e" % (
+        rel(eex["val_mat"], ex["val_mat"]), rel(eex["key_mat"], ex["key_mat"]), rel(eex["query_mat"], ex["query_mat"]),
+        float((eprob - rprob).abs().max()), rel(epred, rpred)))
+    if not torch.cuda.is_available():
+        return
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import engine as eng_mod
+    cfg = {"model": dict(arch="MIMOcom", agent_num=N, shared_img_encoder="unified", attention="general", sparse=False,
+                         query=True, query_size=32, key_size=1024, enc_backbone="resnet_encoder",
+                         dec_backbone="simple_decoder", feat_squeezer=-1, feat_channel=512),
+           "data": {"img_rows": S, "img_cols": S}}
+    m = get_model(cfg, 11)
+    filler.apply_to_module(m)
+    m = m.cuda().eval()
+    eng = eng_mod.CommEngine(m)
+    with torch.no_grad():
+        sq, keys, querys = eng.encode(x.cuda(), N)
+        pred, prob, action, nnz, low = eng.graph_and_decode(sq, keys, querys, B, N, 0, N, "softmax")
+    torch.cuda.synchronize()
+    V = sq.float().cpu()[..., :512].permute(0, 3, 1, 2)                 # agent-major [M,512,h,w]
+    rV = orc.agents2batch(ex["val_mat"])
+    rK = orc.agents2batch(ex["key_mat"])
+    rQ = orc.agents2batch(ex["query_mat"])
+    print("[HIP]                   V rel %.2e  keys rel %.2e  query rel %.2e  P maxabs %.2e  logits rel %.2e  low rel %.2e" % (
+        rel(V, rV), rel(keys.cpu(), rK), rel(querys.cpu(), rQ), float((prob.cpu() - rprob).abs().max()),
+        rel(pred.cpu(), rpred), rel(low.cpu()[..., :11].permute(0, 3, 1, 2), ex["low_logits"])))
+    print("[HIP vs emulated]       V rel %.2e  keys rel %.2e  P maxabs %.2e  logits rel %.2e" % (
+        rel(V, orc.agents2batch(eex["val_mat"])), rel(keys.cpu(), orc.agents2batch(eex["key_mat"])),
+        float((prob.cpu() - eprob).abs().max()), rel(pred.cpu(), epred)))
+    agree = float((pred.cpu().argmax(1) == rpred.argmax(1)).float().mean())
+    print("argmax agreement HIP vs oracle %.4f ; emulated vs oracle %.4f" % (
+        agree, float((epred.argmax(1) == rpred.argmax(1)).float().mean())))
+
+
+if __name__ == "__main__":
+    main()
