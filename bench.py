@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- When2com forward throughput on MI355X (the metric of BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one eval forward (`inference='softmax'`, the single-decode mode) of mrms-when2com on a
+synthetic AirSim-MAP-shaped batch already resident in HBM: per rank B=4 samples x 5 agents x
+512x512 (BASELINE.json configs[1]).  With N ranks the agents are sharded (5 per rank, 5N agents in
+one communication graph) and K/V are all-gathered over RCCL -- weak scaling.  `value` is
+agent-images/s over all ranks (image = one agent frame).
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel w2c_conv_igemm_bf16 (MFMA bound): algorithmic FLOPs of all its
+                  launches in one forward / the sum of their HIP-event durations, vs 2.5 PFLOP/s
+                  dense bf16 (MI355X_MICROARCH.md).  Measured in a separate attribution pass after
+                  the timed region (events around every conv launch on the launch stream).
+  cpu_baseline -- the oracle (oracle/when2com_oracle.py, stock PyTorch CPU fp32 = the ops the
+                  reference bottoms out in; kind "port") timed on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only).
+  parity       -- HIP vs oracle on that same sample: logits rel-L2, argmax agreement, mIoU of both
+                  against the same synthetic labels.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+GFLOP_PER_AGENT_IMAGE_512 = 42.919   # SURVEY.md section 8d (2*MAC, conv+linear)
+
+
+def build_cfg(agent_num, size):
+    return {"model": dict(arch="MIMOcom", agent_num=agent_num, shared_img_encoder="unified", attention="general",
+                          sparse=False, query=True, query_size=32, key_size=1024, enc_backbone="resnet_encoder",
+                          dec_backbone="simple_decoder", feat_squeezer=-1, feat_channel=512, multiple_output=True),
+            "data": {"img_rows": size, "img_cols": size}}
+
+
+def cpu_baseline(x_sample, n_agents, size, labels):
+    """Oracle forward on the host cores; bounded sample (B=1 of the batch)."""
+    from oracle import filler
+    from oracle import when2com_oracle as orc
+    sd = orc.to_torch(filler.fill_state_dict(orc.state_spec("MIMOcom", image_size=size)))
+    run = lambda: orc.mimocom_forward(sd, x_sample, n_agents, training=False, MO_flag=True, inference="softmax")  # noqa: E731
+    # thread count: stock PyTorch CPU convs stop scaling (and collapse, 40+ s/forward) long before a
+    # 256-core host is full, so give the baseline its best setting: try a few counts once, keep the fastest.
+    ncpu = os.cpu_count() or 1
+    best_t, threads = None, 1
+    for cand in sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(cand)
+        run()
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, threads = dt, cand
+        if dt > 8.0:
+            break
+    torch.set_num_threads(threads)
+    times = []
+    t_end = time.perf_counter() + 15.0
+    out = None
+    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 15):
+        t0 = time.perf_counter()
+        out = run()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    imgs = x_sample.shape[0] * n_agents
+    miou = orc.mean_iou(orc.confusion_matrix(labels, out[0].max(1)[1].numpy()))
+    return dict(value=imgs / med, unit="agent-images/s", cores=threads, kind="port", host_cpus=ncpu,
+                sample="B=1 x %d agents x %dx%d, %d timed forwards, median %.3f s, torch CPU fp32, %d threads "
+                       "(fastest of 8/16/32/64/128)" % (n_agents, size, size, len(times), med, threads)), out, miou
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--agents-per-gpu", type=int, default=5)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="softmax", choices=["softmax", "argmax_test", "activated"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the measured path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from oracle import filler                     # weights/inputs generator shared with the parity fixtures
+    from ptsemseg.models import get_model          # the reference's import path
+    from multiagentperception_amd import ops
+    from multiagentperception_amd.parallel import AgentParallelForward
+
+    B, n_loc, S = args.batch, args.agents_per_gpu, args.size
+    N = n_loc * world
+    model = get_model(build_cfg(N, S), 11)
+    filler.apply_to_module(model)
+    model = model.to(dev).eval()
+    frames = filler.synthetic_frames(B, n_loc, S, S, 1234 + 2 + rank)          # cfg 2 seed + rank
+    x = torch.from_numpy(frames).to(dev)
+    fwd = AgentParallelForward(model)
+
+    def step():
+        return fwd(x, inference=args.mode)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    images_per_step = B * N
+    value = images_per_step * args.steps / elapsed
+
+    # ---- roofline attribution pass (dominant kernel), outside the timed region -------------------
+    timer = ops.KernelTimer()
+    ops.set_conv_timer(timer)
+    reps = 3
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize(dev)
+    ops.set_conv_timer(None)
+    conv_ms, conv_fl, launches, per_shape = timer.summary()
+    conv_ms /= reps
+    conv_fl /= reps
+    launches //= reps
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    flop_per_img = GFLOP_PER_AGENT_IMAGE_512 * (S / 512.0) ** 2
+    roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    launches_per_step=launches, kernel_ms_per_step=round(conv_ms, 4),
+                    algorithmic_gflop_per_step=round(conv_fl / 1e9, 2),
+                    whole_forward_tflops=round(value * flop_per_img / 1e3, 2),
+                    whole_forward_frac=round(value * flop_per_img / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+
+    result = dict(metric="forward agent-images/sec, 5-agent 512x512 mrms-when2com", value=round(value, 2),
+                  unit="agent-images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                  ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                  dtype="bf16", data="synthetic",
+                  config=dict(workload="mrms-when2com MIMOcom forward (eval, inference=%s), %d agents/GPU x B=%d x %dx%d, "
+                                       "agent-parallel K/V all-gather" % (args.mode, n_loc, B, S, S),
+                              agents_total=N, global_batch=B, frames_per_s=round(B * args.steps / elapsed, 2),
+                              parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)"),
+                  roofline=roofline)
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, single GPU only) ---------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import when2com_oracle as orc
+        xs = torch.from_numpy(frames[:1])
+        labels = filler.synthetic_labels(N, S, S, 1234 + 2)
+        base, ref_out, ref_miou = cpu_baseline(xs, N, S, labels)
+        hip = model(xs.to(dev), training=False, MO_flag=True, inference="softmax")
+        hp = hip[0].cpu()
+        rp = ref_out[0]
+        hip_miou = orc.mean_iou(orc.confusion_matrix(labels, hp.max(1)[1].numpy()))
+        agree_labels = rp.max(1)[1].numpy()
+        result["cpu_baseline"] = base
+        result["parity"] = dict(
+            logits_rel_l2=float(np.linalg.norm(hp.numpy() - rp.numpy()) / np.linalg.norm(rp.numpy())),
+            argmax_agreement=float((hp.argmax(1) == rp.argmax(1)).float().mean()),
+            prob_max_abs=float((hip[1].cpu() - ref_out[1]).abs().max()),
+            miou_vs_synthetic_labels=dict(hip=hip_miou, oracle=ref_miou, delta=hip_miou - ref_miou),
+            miou_hip_vs_oracle_argmax=orc.mean_iou(orc.confusion_matrix(agree_labels, hp.max(1)[1].numpy())))
+        result["speedup_vs_cpu"] = round(value / base["value"], 1)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -179,10 +179,9 @@ class CommEngine:
         self.decoder = DecoderPlan(model.decoder, self.n_classes)
         self.feat = 512
 
-    def encode(self, x, n_agents):
-        """-> sq (bf16 NHWC [n*B,h,w,1024]: V in [0,512), policy-encoder map in [512,1024)),
-        keys f32 [n*B,Dk], queries f32 [n*B,Dq] or None."""
-        sq = self.trunk.run(x, n_agents)
+    def policy_tail(self, sq):
+        """policy_net4 conv1..5 + key/query heads on the policy-encoder half of `sq` (agent.py:137-141,
+        1126-1129) -> keys f32 [n*B,Dk], queries f32 [n*B,Dq] or None."""
         y = self.policy[0].run(sq, x_ch_off=self.feat)
         for c in self.policy[1:]:
             y = c.run(y)
@@ -193,6 +192,13 @@ class CommEngine:
                 self.query_head = HeadPlan(self._model_heads[1], hw)
         keys = self.key_head.run(y)
         querys = self.query_head.run(y) if self.query_head is not None else None
+        return keys, querys
+
+    def encode(self, x, n_agents):
+        """-> sq (bf16 NHWC [n*B,h,w,1024]: V in [0,512), policy-encoder map in [512,1024)),
+        keys f32 [n*B,Dk], queries f32 [n*B,Dq] or None."""
+        sq = self.trunk.run(x, n_agents)
+        keys, querys = self.policy_tail(sq)
         return sq, keys, querys
 
     def graph_and_decode(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):

@@ -37,6 +37,36 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+class KernelTimer:
+    """Opt-in per-launch timing of the dominant kernel (w2c_conv_igemm_bf16) with HIP events on
+    the launch stream (torch.cuda.Event on torch's current stream == the stream we launch on).
+    Used by bench.py's roofline attribution pass only; never active inside its timed region."""
+
+    def __init__(self):
+        self.records = []          # (start_event, end_event, flops, key)
+
+    def summary(self):
+        """-> total_ms, total_flops, launches, per-shape {key: [ms, flops, count]} (call after a sync)."""
+        total_ms, total_fl, per = 0.0, 0.0, {}
+        for st, en, fl, key in self.records:
+            ms = st.elapsed_time(en)
+            total_ms += ms
+            total_fl += fl
+            e = per.setdefault(key, [0.0, 0.0, 0])
+            e[0] += ms
+            e[1] += fl
+            e[2] += 1
+        return total_ms, total_fl, len(self.records), per
+
+
+_conv_timer = None
+
+
+def set_conv_timer(timer):
+    global _conv_timer
+    _conv_timer = timer
+
+
 _zero_pages = {}
 
 
@@ -92,11 +122,20 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     if residual is not None and tuple(residual.shape) != tuple(out.shape):
         raise W2CError("conv: residual geometry must equal the output geometry")
     xptr = x.data_ptr() + 2 * x_ch_off
+    timer = _conv_timer
+    if timer is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
     with torch.cuda.device(dev):
         check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
                                                 _p(scale), _p(shift), _p(residual), 1 if relu else 0,
                                                 _p(out), out_cstride, 1 if out_f32 else 0,
                                                 _p(zero_page(dev)), _stream(dev)), "w2c_conv_igemm_bf16")
+    if timer is not None:
+        ev1.record(torch.cuda.current_stream(dev))
+        flops = 2.0 * M * Ho * Wo * cout * (ksize * ksize * cin) * groups
+        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups)))
     return out
 
 

@@ -60,12 +60,17 @@ def canonical_name(name):
     return name
 
 
-def _gain(name):
+def _gain(name, fan_in=None):
     """Per-tensor gain overrides (everything else is He/Glorot-like)."""
     # query head + attention projection: a 3x total gain makes softmax_k(key . W q)
     # peaked (max P ~0.5-0.9) while keeping |score| ~10, so that 'activated'
     # (P > 0.2, agent.py:1060-1062) is not a knife-edge on every entry AND the
     # fixture does not amplify bf16 rounding of the keys (delta_score ~ 6e-3 * |score|).
+    # key/query heads' first layer sees n_feat = 256*(H/128)^2 ReLU (non-zero-mean) inputs, so its
+    # output grows with image size; (256/fan_in)^0.35 keeps key/query statistics -- and hence the
+    # score magnitudes that set the bf16 sensitivity of P -- alike from 128^2 to 1024^2.
+    if name.endswith("_net.fc.0.weight") and fan_in is not None and fan_in > 256:
+        return (256.0 / fan_in) ** 0.35
     if name.endswith("query_net.fc.4.weight"):
         return 1.5
     if name.endswith("attention_net.linear.weight"):
@@ -85,7 +90,7 @@ def fill_array(name, shape):
     if name.endswith("num_batches_tracked"):
         return np.zeros(shape, dtype=np.int64)
     u = uniform_pm1(name, n)
-    g = _gain(name)
+    g = _gain(name, shape[1] if len(shape) == 2 else None)
     if name.endswith("running_var"):
         v = 1.0 + 0.4 * u                      # in [0.6, 1.4)
     elif name.endswith("running_mean"):

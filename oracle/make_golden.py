@@ -31,6 +31,8 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
 from oracle import filler  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import diag_forward as diag  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 MARGIN = 0.04
@@ -182,7 +184,21 @@ def run_case(ref_models, ref_metrics, name, arch, yml, agent_num, batch, size, m
                 _, p_try, _, _ = model(x, training=False, MO_flag=True, inference="softmax")
             top2 = p_try.topk(2, dim=1)[0]
             if float((p_try - 0.2).abs().min()) >= MARGIN and float((top2[:, 0] - top2[:, 1]).min()) >= MARGIN:
-                break
+                # also require the fixture to be well conditioned for ANY bf16-storage pipeline: the
+                # oracle with conv operands / ReLU outputs rounded to bf16 (tools/diag_forward.py) must
+                # itself stay well inside the stated GPU tolerances.
+                from oracle import when2com_oracle as orc
+                sd = orc.to_torch(filler.fill_state_dict(orc.state_spec(arch, image_size=size, has_query=hasattr(model, "query_net"))))
+                fwd = orc.mimocom_forward if arch == "MIMOcom" else orc.mimocomwho_forward
+                (e_pred, e_prob, _, _), _ = diag.emulated(sd, x, agent_num, has_query=hasattr(model, "query_net"), fwd=fwd)
+                r_pred, r_prob, _, _ = fwd(sd, x, agent_num, training=False, MO_flag=True, inference="softmax",
+                                           has_query=hasattr(model, "query_net"))
+                p_err = float((e_prob - r_prob).abs().max())
+                l_err = diag.rel(e_pred, r_pred)
+                if p_err <= 8e-3 and l_err <= 6.5e-3:
+                    meta["emulated_bf16_p_err"] = p_err
+                    meta["emulated_bf16_logits_rel"] = l_err
+                    break
         else:
             raise RuntimeError("no seed with margin for " + name)
         meta["seed"] = seed
@@ -252,6 +268,19 @@ def main():
         json.dump(metas, fp, indent=1)
     with open(os.path.join(GOLD, "state_spec.json"), "w") as fp:
         json.dump(specs, fp)
+    # row M: the reference's runningScore on hashed labels/predictions (incl. ignore label 250)
+    lt = filler.synthetic_labels(4, 64, 64, 5)
+    lp = filler.synthetic_labels(4, 64, 64, 6)
+    lt[filler.synthetic_labels(4, 64, 64, 7) == 0] = 250            # ~9 % ignored pixels (loss.py:15-17 ignore_index)
+    lp[:, :, :8] = 3                                                # skewed predictions: some classes never predicted
+    lp[lp == 9] = 2
+    rs = ref_metrics.runningScore(11)
+    rs.update(lt, lp)
+    sc, cls_iu = rs.get_scores()
+    np.savez_compressed(os.path.join(GOLD, "metrics_unit.npz"), hist=rs.confusion_matrix,
+                        miou=np.float64(sc["Mean IoU : \t"]), acc=np.float64(sc["Overall Acc: \t"]),
+                        mean_acc=np.float64(sc["Mean Acc : \t"]), fwacc=np.float64(sc["FreqW Acc : \t"]),
+                        cls_iu=np.array([cls_iu[i] for i in range(11)], dtype=np.float64))
     # 512x512 state spec + parameter counts without running a forward
     counts = {}
     for arch, yml, over in (("MIMOcom", "multi-request-multi-support/mrms_when2com.yml", {}),

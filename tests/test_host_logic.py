@@ -1,0 +1,149 @@
+"""CPU: host-side logic of the drop-in (module API, state_dict layout, weight packing math, error
+behaviour).  No kernels run here."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import filler
+from oracle import when2com_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cfg(arch, n=5, size=512, query=True):
+    return {"model": dict(arch=arch, agent_num=n, shared_img_encoder="unified", attention="general", sparse=False,
+                          query=query, query_size=32, key_size=1024, enc_backbone="resnet_encoder",
+                          dec_backbone="simple_decoder", feat_squeezer=-1, feat_channel=512, shuffle_features=None),
+            "data": {"img_rows": size, "img_cols": size}}
+
+
+@pytest.mark.parametrize("arch,query", [("MIMOcom", True), ("MIMOcomWho", False), ("Single_agent", True)])
+def test_state_dict_is_key_for_key_the_references(arch, query):
+    from ptsemseg.models import get_model
+    ref = json.load(open(os.path.join(GOLD, "state_spec_512.json")))[arch]
+    m = get_model(_cfg(arch, query=query), 11)
+    mine = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == [(k, v) for k, v in ref["spec"]]                  # names, shapes AND order
+    assert sum(p.numel() for p in m.parameters()) == ref["n_param"]
+    # aliased ResNet keys share storage (backbone.py:63-69)
+    sd = m.state_dict()
+    pre = "encoder." if arch == "Single_agent" else "u_encoder."
+    a = sd[pre + "feature_backbone.backbone_0.weight"]
+    b = sd[pre + "feature_backbone.feature_backbone.conv1.weight"]
+    assert a.data_ptr() == b.data_ptr()
+
+
+def test_reference_checkpoint_roundtrip_and_convert_state_dict_prefix():
+    """trainer.py:770-772: convert_state_dict strips 'module.' then load_state_dict(strict=False)."""
+    from ptsemseg.models import get_model
+    m = get_model(_cfg("MIMOcom", n=2, size=128), 11)
+    sd = {"module." + k: torch.from_numpy(filler.fill_array(k, tuple(v.shape))) for k, v in m.state_dict().items()}
+    stripped = {k[7:]: v for k, v in sd.items()}
+    missing, unexpected = m.load_state_dict(stripped, strict=False)
+    assert not missing and not unexpected
+    np.testing.assert_array_equal(m.state_dict()["decoder.output_decoder.pred.2.bias"].numpy(),
+                                  filler.fill_array("decoder.output_decoder.pred.2.bias", (11,)))
+
+
+def test_eval_forward_refuses_cpu_and_bad_modes():
+    from ptsemseg.models import get_model
+    from multiagentperception_amd._native import W2CError
+    m = get_model(_cfg("MIMOcom", n=2, size=128), 11).eval()
+    x = torch.zeros(1, 6, 128, 128)
+    with pytest.raises(W2CError, match="no CPU fallback"):
+        m(x, training=False, MO_flag=True, inference="softmax")
+    with pytest.raises(ValueError, match="Incorrect inference mode"):
+        m(x, training=False, MO_flag=True, inference="nope")
+    m.shared_img_encoder = False
+    with pytest.raises(ValueError, match="Incorrect encoder"):
+        m(x, training=False, MO_flag=True, inference="softmax")
+    s = get_model(_cfg("Single_agent"), 11).eval()
+    with pytest.raises(W2CError):
+        s(torch.zeros(1, 3, 128, 128))
+
+
+def test_registry_errors_match_reference_shapes():
+    from ptsemseg.models import get_model
+    with pytest.raises(TypeError):                       # reference: `raise (str)` -> TypeError (models/__init__.py:100-101)
+        get_model(_cfg("NoSuchModel"), 11)
+    with pytest.raises(NotImplementedError):
+        get_model(_cfg("LearnWhen2Com"), 11)
+    with pytest.raises(ValueError, match="Incorrect shared_img_encoder flag"):
+        c = _cfg("MIMOcomWho")
+        c["model"]["shared_img_encoder"] = False
+        get_model(c, 11)
+
+
+def test_bn_fold_and_weight_packing_math():
+    """engine._fold_bn / _pack_w / stem pack / head column permutation reproduce the reference ops."""
+    from multiagentperception_amd import engine
+    from multiagentperception_amd.models import blocks
+    gen = torch.Generator().manual_seed(0)
+    cbr = blocks.conv2DBatchNormRelu(64, 32, 3, 1, 1)
+    filler.apply_to_module(cbr)
+    cbr.eval()
+    x = torch.randn(2, 64, 6, 6, generator=gen)
+    conv, bn = cbr.cbr_unit[0], cbr.cbr_unit[1]
+    scale, shift = engine._fold_bn(bn, conv.bias)
+    ref = cbr(x)
+    got = F.relu(F.conv2d(x, conv.weight, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), atol=1e-5)
+    # packed weight layout [Cout][ky][kx][Cin]
+    wp = engine._pack_w(conv.weight).float().reshape(32, 3, 3, 64)
+    np.testing.assert_array_equal(wp.numpy(), conv.weight.detach().to(torch.bfloat16).float().permute(0, 2, 3, 1).numpy())
+    # head: NHWC-flattened input x permuted fc.0 == NCHW-flattened input x original fc.0
+    head = blocks.km_generator(out_size=32, input_feat_sz=256 / 32)      # n_feat = 256*2*2
+    filler.apply_to_module(head)
+    hp = engine.HeadPlan(head, hw=4)
+    fmap = torch.randn(3, 256, 2, 2, generator=gen)
+    ref = F.linear(fmap.reshape(3, -1), head.fc[0].weight, head.fc[0].bias)
+    got = F.linear(fmap.permute(0, 2, 3, 1).reshape(3, -1), hp.w0, hp.b0)
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), atol=1e-5)
+
+
+def test_two_trunk_plan_interleaves_u_encoder_and_policy_encoder():
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import engine
+    m = get_model(_cfg("MIMOcom", n=2, size=128), 11)
+    filler.apply_to_module(m)
+    tp = engine.TrunkPlan([m.u_encoder, m.query_key_net.img_encoder])
+    assert tp.G == 2 and tuple(tp.stem_w.shape) == (128, 224)
+    c1 = tp.blocks[0][0]
+    assert c1.groups == 2 and tuple(c1.w.shape) == (2, 64, 576)
+    u = m.u_encoder.feature_backbone.feature_backbone.layer1[0].conv1.weight
+    p = m.query_key_net.img_encoder.feature_backbone.feature_backbone.layer1[0].conv1.weight
+    np.testing.assert_array_equal(c1.w[0].float().numpy(), engine._pack_w(u).float().numpy())
+    np.testing.assert_array_equal(c1.w[1].float().numpy(), engine._pack_w(p).float().numpy())
+    # stem padding taps / channel are exactly zero
+    sw = tp.stem_w.float().reshape(128, 7, 8, 4)
+    assert float(sw[:, :, 7, :].abs().max()) == 0.0 and float(sw[:, :, :, 3].abs().max()) == 0.0
+
+
+def test_engine_cache_invalidation_rules():
+    from ptsemseg.models import get_model
+    m = get_model(_cfg("MIMOcom", n=2, size=128), 11)
+    m._engines[0] = object()
+    m.train()
+    assert not m._engines
+    m._engines[0] = object()
+    m.load_state_dict(m.state_dict())
+    assert not m._engines
+    m._engines[0] = object()
+    m.float()
+    assert not m._engines
+
+
+def test_train_mode_stock_op_path_keeps_reference_return_tuple():
+    """module.train(): batch-stat BN + autograd run on stock ops (outside the accelerated scope);
+    return tuple and shapes follow agent.py:1170-1174."""
+    from ptsemseg.models import get_model
+    m = get_model(_cfg("MIMOcom", n=2, size=128), 11).train()
+    x = torch.randn(2, 6, 128, 128)
+    pred, prob, action, nconn = m(x, training=True, MO_flag=True)
+    assert pred.shape == (4, 11, 128, 128) and prob.shape == (2, 2, 2) and action.shape == (2, 2) and nconn == 1
+    pred.mean().backward()
+    assert m.decoder.output_decoder.pred[2].weight.grad is not None
