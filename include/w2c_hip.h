@@ -79,6 +79,15 @@ int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_c
                         void* y, int y_cstride, int y_is_f32,
                         const void* zero_page, w2c_stream_t stream);
 
+/* Same contract, with the tile/pipeline variant forced (index into the table in csrc/conv_igemm.hip).
+ * For tuning (tools/bench_conv.py) and tests; results are bit-identical across variants. */
+int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                const uint16_t* w, int Cout, int ksize, int stride, int groups,
+                                const float* scale, const float* shift,
+                                const uint16_t* residual, int relu,
+                                void* y, int y_cstride, int y_is_f32,
+                                const void* zero_page, int variant, w2c_stream_t stream);
+
 /* ---- K5: Linear (+ReLU) for the key/query heads (agent.py:150-159,167-178).
  * x : [M, K] bf16 (x_is_bf16=1, row stride x_stride elements) or f32
  * w : f32 [O, K] row-major; b : f32 [O]; y : f32 [M, O].  K multiple of 4, M <= 64 per call. */

@@ -75,6 +75,60 @@ __global__ __launch_bounds__(256) void linear_kernel(const void* __restrict__ xv
     }
 }
 
+// Wide-K form (K >= 1024, i.e. fc.0 on the flattened policy map): one WORKGROUP per output column;
+// the 256 threads split K (coalesced 16-B reads of the weight row and of every input row, which is
+// L2-resident: M*K*2 bytes), MR rows accumulate per pass, then wave shuffle + cross-wave LDS
+// reduction.  The one-wave-per-output form above serialises K/256 dependent iterations per row and
+// ran 76 us for M=20, K=4096, O=256 (r01_a profile); this form is bound by the 4 MB weight read.
+template <int MR, bool XBF16>
+__global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restrict__ xv, int x_stride, int M, int K,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int O, int relu, float* __restrict__ y) {
+    __shared__ float red[4][MR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o = blockIdx.x;
+    const float* wrow = w + (size_t)o * K;
+    for (int m0 = 0; m0 < M; m0 += MR) {
+        float acc[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) acc[r] = 0.f;
+        for (int k = tid * 4; k < K; k += 1024) {
+            const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wrow + k);
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                const int m = m0 + r < M ? m0 + r : M - 1;          // clamp: branch-free, duplicates discarded below
+                float x0, x1, x2, x3;
+                if (XBF16) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(
+                        reinterpret_cast<const uint16_t*>(xv) + (size_t)m * x_stride + k);
+                    x0 = bf16_to_f32((uint16_t)(u.x & 0xFFFFu)); x1 = bf16_to_f32((uint16_t)(u.x >> 16));
+                    x2 = bf16_to_f32((uint16_t)(u.y & 0xFFFFu)); x3 = bf16_to_f32((uint16_t)(u.y >> 16));
+                } else {
+                    const f32x4_t u = *reinterpret_cast<const f32x4_t*>(
+                        reinterpret_cast<const float*>(xv) + (size_t)m * x_stride + k);
+                    x0 = u[0]; x1 = u[1]; x2 = u[2]; x3 = u[3];
+                }
+                acc[r] = fmaf(x0, wv[0], acc[r]);
+                acc[r] = fmaf(x1, wv[1], acc[r]);
+                acc[r] = fmaf(x2, wv[2], acc[r]);
+                acc[r] = fmaf(x3, wv[3], acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const float sres = wave_sum(acc[r]);
+            if (lane == 0) red[wave][r] = sres;
+        }
+        __syncthreads();
+        if (tid < MR && m0 + tid < M) {
+            float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + bias[o];
+            if (relu) v = fmaxf(v, 0.f);
+            y[(size_t)(m0 + tid) * O + o] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- K6: communication graph
 // score[k][q] = key[k] . (Wq query[q] + bq) = (Wq^T key[k]) . query[q] + key[k] . bq
 // so only T[k] = Wq^T key[k] (Dq values) and t0[k] = key[k].bq are formed: N*Dk*Dq MACs and no
@@ -97,9 +151,16 @@ __global__ __launch_bounds__(256) void key_project_kernel(const float* __restric
     const int parts = 256 / Dq;                            // Dq <= 256
     const int j = tid % Dq, part = tid / Dq;
     if (part < parts) {
-        float s = 0.f;
-        for (int d = part; d < Dk; d += parts) s = fmaf(wq[(size_t)d * Dq + j], krow[d], s);
-        red[part * Dq + j] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 independent chains: loads stay in flight
+        int d = part;
+        for (; d + 3 * parts < Dk; d += 4 * parts) {
+            s0 = fmaf(wq[(size_t)d * Dq + j], krow[d], s0);
+            s1 = fmaf(wq[(size_t)(d + parts) * Dq + j], krow[d + parts], s1);
+            s2 = fmaf(wq[(size_t)(d + 2 * parts) * Dq + j], krow[d + 2 * parts], s2);
+            s3 = fmaf(wq[(size_t)(d + 3 * parts) * Dq + j], krow[d + 3 * parts], s3);
+        }
+        for (; d < Dk; d += parts) s0 = fmaf(wq[(size_t)d * Dq + j], krow[d], s0);
+        red[part * Dq + j] = (s0 + s1) + (s2 + s3);
     }
     // bias column: every wave takes a strided share, wave 0 finishes
     float sb = 0.f;
@@ -237,6 +298,13 @@ extern "C" int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M,
     w2c_clear_error();
     if (!x || !w || !b || !y || M <= 0 || K <= 0 || O <= 0 || (K % 4) != 0 || (x_stride % 4) != 0) return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (K >= 1024) {
+        if (x_is_bf16)
+            hipLaunchKernelGGL((linear_widek_kernel<8, true>), dim3(O), dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+        else
+            hipLaunchKernelGGL((linear_widek_kernel<8, false>), dim3(O), dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+        return w2c_launch_status();
+    }
     dim3 grid((O + 3) / 4);
     if (x_is_bf16)
         hipLaunchKernelGGL((linear_kernel<16, true>), grid, dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);

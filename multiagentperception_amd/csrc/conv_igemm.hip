@@ -8,22 +8,25 @@
 // GEMM view:  D[pixel][cout] = sum_{tap,ci} X[pixel @ tap][ci] * Wt[cout][tap][ci]
 //   rows   = output pixels (M*Ho*Wo, NHWC order => a row IS the output pixel index)
 //   cols   = output channels of one group
-//   K      = ksize*ksize*Cin, walked as (tap, 64-channel chunk): NHWC makes every K-step of a
-//            row one contiguous 128-byte run, so the im2col gather is a per-lane ADDRESS, never
-//            a materialised matrix.
-// Per workgroup (256 threads = 4 waves, one per SIMD): a BM x BN tile, K-step 64.
-//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, the LDS
-//     image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and
-//     again on the ds_read -- cdna_hip_programming.md rule 21).  Padded taps read a zero page.
-//   * two LDS stages; the DMA of K-step t+1 is in flight while step t's MFMAs run; one barrier
-//     per K-step.
-//   * v_mfma_f32_32x32x16_bf16, f32 accumulate; A = pixels, B = channels.
+//   K      = ksize*ksize*Cin, walked as (tap, BK-channel chunk): NHWC makes every K-step of a
+//            row one contiguous run of BK*2 bytes, so the im2col gather is a per-lane ADDRESS
+//            (row base + a wave-uniform tap offset), never a materialised matrix.
+// Per workgroup (64*WM*WN threads): a BM x BN tile.
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 B per lane; the LDS image
+//     is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and again on
+//     the ds_read -- cdna_hip_programming.md rule 21).  Padded taps read a zero page.
+//   * STAGES-deep LDS ring: the DMA of K-step t+STAGES-1 is issued at step t, so STAGES-2 full
+//     steps of MFMA work cover the L2/HBM latency; waits are counted (s_waitcnt vmcnt(N), never a
+//     drain in steady state) and there is ONE raw s_barrier per K-step (it publishes tile t and
+//     retires the buffer tile t-1 was read from).
+//   * all ds_read_b128 of a K-step are issued ahead of its MFMAs (compiler emits counted lgkmcnt);
+//     v_mfma_f32_32x32x16_bf16, f32 accumulate; A = pixels, B = channels.
 //   * epilogue: per-channel scale/shift (eval BN or bias) in registers, tile staged through LDS as
 //     f32 so the residual read and the bf16/f32 store are 16-byte coalesced along channels.
-// LDS swizzle: rows are 128 B (64 bf16); chunk c (16 B) of row r lives at position
-// c ^ ((r >> 1) & 7).  ds_read_b128 is serviced in 16-lane groups over a 256-B bank row (= two
-// of our rows); this XOR makes each group's 16 (row parity, position) pairs distinct => no
-// bank conflicts (MI355X_MICROARCH.md LDS table).
+// LDS swizzle (rows of BK*2 bytes, 16-B chunks): BK=64: chunk c of row r at c ^ ((r>>1)&7);
+// BK=32: c ^ ((r>>2)&3).  ds_read_b128 is serviced in 16-lane groups over a 256-B bank row; these
+// XORs make each group's 16 (row-in-bank-row, position) pairs distinct => conflict-free
+// (MI355X_MICROARCH.md LDS table).
 #include "w2c_common.h"
 
 namespace {
@@ -41,25 +44,34 @@ struct ConvArgs {
     int ks, stride, pad;
     int relu, y_f32;
     int rows;        // M*Ho*Wo
-    int cin_tiles;   // Cin / 64
+    int cin_tiles;   // Cin / BK
     int ktiles;      // ks*ks*cin_tiles
     int ntm, ntn;    // tiles along rows / cout
 };
 
-constexpr int BK = 64;                 // K-step (bf16 elements) = 128 B per row
-constexpr int ROWB = BK * 2;           // bytes per LDS row
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+template <int BM, int BN, int WM, int WN, int BK, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;        // wave tile
     constexpr int MI = WTM / 32, NI = WTN / 32;        // 32x32 MFMA tiles per wave
-    constexpr int A_INSTR = BM / 32;                   // LDS-DMA instructions per wave per K-step (8 rows each)
-    constexpr int B_INSTR = BN / 32;
+    constexpr int ROWB = BK * 2;                       // bytes per LDS row
+    constexpr int LPR = ROWB / 16;                     // lanes (16-B chunks) per row: 8 or 4
+    constexpr int RPI = 64 / LPR;                      // rows per DMA wave-instruction: 8 or 16
+    constexpr int A_INSTR = BM / RPI / NW;             // DMA instructions per wave per K-step
+    constexpr int B_INSTR = BN / RPI / NW;
+    constexpr int LOADS = A_INSTR + B_INSTR;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int KSUB = BK / 16;                      // MFMA K-steps per stage
     constexpr int CLD = BN + 4;                        // f32 epilogue tile leading dim
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(2 * STAGE_BYTES >= 0, "");
+    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1 && A_INSTR * RPI * NW == BM && B_INSTR * RPI * NW == BN, "DMA split");
+    static_assert(STAGES >= 2 && (STAGES - 2) * LOADS < 64, "vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,19 +86,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     const uint16_t* xg = p.x + (size_t)g * p.Cin;                      // group's channel slice
-    const uint16_t* wg = p.w + (size_t)g * p.Cout * (p.ktiles * BK);   // group's weights
     const int Ktot = p.ktiles * BK;
+    const uint16_t* wg = p.w + (size_t)g * p.Cout * Ktot;              // group's weights
 
     // ---- per-thread gather state for its A rows (fixed for the whole K loop) ----
-    const int lrow = lane >> 3;            // row within an 8-row DMA group
-    const int lpos = lane & 7;             // 16-B position within the 128-B LDS row
-    int a_iy0[A_INSTR], a_ix0[A_INSTR], a_chunk[A_INSTR];
-    long a_img[A_INSTR];                   // element offset of image start, or -1 when the row is past the end
+    const int lrow = lane / LPR;           // row within a DMA group
+    const int lpos = lane % LPR;           // 16-B position within the LDS row
+    auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    int a_iy0[A_INSTR], a_ix0[A_INSTR];
+    long a_off[A_INSTR];                   // element offset of (image, iy0, ix0) + chunk; row validity folded into iy0
+    int a_zoff[A_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-        const int r = (wave + 4 * j) * 8 + lrow;
+        const int r = (wave + NW * j) * RPI + lrow;
         const int gr = m0 + r;
-        a_chunk[j] = lpos ^ ((r >> 1) & 7);
+        const int chunk = lpos ^ swz(r);
+        a_zoff[j] = chunk * 8;
         if (gr < p.rows) {
             const int hw = p.Ho * p.Wo;
             const int m = gr / hw;
@@ -94,40 +109,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_iy0[j] = oy * p.stride - p.pad;
             a_ix0[j] = ox * p.stride - p.pad;
-            a_img[j] = (long)m * p.H * p.W;
+            a_off[j] = ((long)m * p.H * p.W + (long)a_iy0[j] * p.W + a_ix0[j]) * p.xcs + chunk * 8;
         } else {
-            a_iy0[j] = 0; a_ix0[j] = 0; a_img[j] = -1;
+            a_iy0[j] = -100000; a_ix0[j] = 0; a_off[j] = 0;       // every tap out of range -> zero page
         }
     }
     const uint16_t* b_src[B_INSTR];
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
-        const int n = (wave + 4 * j) * 8 + lrow;
-        const int chunk = lpos ^ ((n >> 1) & 7);
+        const int n = (wave + NW * j) * RPI + lrow;
+        const int chunk = lpos ^ swz(n);
         b_src[j] = wg + (size_t)(n0 + n) * Ktot + chunk * 8;
     }
 
-    // K-step cursor (wave-uniform): tap (ky,kx) and channel chunk c0
+    // K-step cursor (wave-uniform): tap (ky,kx) and channel chunk
     int st_ky = 0, st_kx = 0, st_ct = 0, st_kt = 0;
 
     auto stage = [&](int buf) {
         char* As = smem + buf * STAGE_BYTES;
         char* Bs = As + A_BYTES;
-        const int c0 = st_ct * BK;
+        const long tap_off = ((long)st_ky * p.W + st_kx) * p.xcs + st_ct * BK;     // wave-uniform
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
             const int iy = a_iy0[j] + st_ky, ix = a_ix0[j] + st_kx;
-            const bool ok = (a_img[j] >= 0) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-            const uint16_t* src = ok ? xg + (size_t)(a_img[j] + (long)iy * p.W + ix) * p.xcs + c0 + a_chunk[j] * 8
-                                     : p.zeros + a_chunk[j] * 8;
-            __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(As + (wave + 4 * j) * 1024), 16, 0, 0);
+            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const uint16_t* real = xg + (a_off[j] + tap_off);
+            const uint16_t* zero = p.zeros + a_zoff[j];
+            const uint16_t* src = ok ? real : zero;
+            __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(As + (wave + NW * j) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j) {
             __builtin_amdgcn_global_load_lds(W2C_GPTR(b_src[j] + (size_t)st_kt * BK),
-                                             W2C_LPTR(Bs + (wave + 4 * j) * 1024), 16, 0, 0);
+                                             W2C_LPTR(Bs + (wave + NW * j) * 1024), 16, 0, 0);
         }
-        // advance cursor
         ++st_kt;
         if (++st_ct == p.cin_tiles) {
             st_ct = 0;
@@ -145,41 +160,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int swz = (l31 >> 1) & 7;        // (row >> 1) & 7 for every row this lane reads (tile offsets are multiples of 32)
+    const int lswz = swz(l31);             // tile / wave offsets are multiples of 32: swz(row) == swz(l31)
 
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE_BYTES;
         const char* Bs = As + A_BYTES;
+        bf16x8_t a[KSUB][MI], b[KSUB][NI];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {               // four K=16 sub-steps
-            const int pos = ((kk * 2 + lhi) ^ swz) << 4;
-            bf16x8_t a[MI], b[NI];
+        for (int kk = 0; kk < KSUB; ++kk) {
+            const int pos = ((kk * 2 + lhi) ^ lswz) << 4;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WTM + i * 32 + l31) * ROWB + pos);
+                a[kk][i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WTM + i * 32 + l31) * ROWB + pos);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WTN + j * 32 + l31) * ROWB + pos);
+                b[kk][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WTN + j * 32 + l31) * ROWB + pos);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
     };
 
-    // ---- main loop: DMA of step t+1 overlaps the MFMAs of step t; one barrier per step ----
-    stage(0);
-    __syncthreads();           // (emits vmcnt(0): the DMA is a pending LDS write)
-    int cur = 0;
-    for (int t = 0; t < p.ktiles - 1; ++t) {
-        stage(cur ^ 1);
-        compute(cur);
-        __syncthreads();
-        cur ^= 1;
+    // ---- main loop: STAGES-deep ring, counted waits, one barrier per K-step ----
+    const int KT = p.ktiles;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < KT) stage(s);
+    int rd = 0;                      // buffer holding tile t
+    int wr = STAGES - 1;             // buffer the next DMA goes to (== buffer of tile t-1)
+    for (int t = 0; t < KT; ++t) {
+        if (t + STAGES - 2 < KT) wait_vmcnt<(STAGES - 2) * LOADS>();     // tile t (my part) has landed
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                    // everyone's part landed; tile t-1's buffer is free
+        if (t + STAGES - 1 < KT) stage(wr);
+        compute(rd);
+        rd = (rd + 1 == STAGES) ? 0 : rd + 1;
+        wr = (wr + 1 == STAGES) ? 0 : wr + 1;
     }
-    compute(cur);
-    __syncthreads();           // every wave done reading the staging buffers; reuse LDS for the epilogue
+    __builtin_amdgcn_s_barrier();    // every wave done reading the ring; reuse LDS for the epilogue
 
     // ---- epilogue 1: scale/shift in registers, tile -> LDS as f32 [BM][CLD] ----
     float* Cs = reinterpret_cast<float*>(smem);
@@ -201,10 +223,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     // ---- epilogue 2: coalesced (+residual) (+ReLU) store, 8 channels per thread per pass ----
     constexpr int CG = BN / 8;                     // 8-channel groups per row
-    constexpr int PASSES = BM * CG / 256;
+    constexpr int PASSES = BM * CG / NT;
+    static_assert(PASSES * NT == BM * CG, "epilogue split");
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-        const int idx = ps * 256 + tid;
+        const int idx = ps * NT + tid;
         const int r = idx / CG, cg = idx - r * CG;
         const int gr = m0 + r;
         if (gr >= p.rows) continue;
@@ -238,30 +261,354 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-constexpr int conv_lds_bytes() {
-    constexpr int stage2 = 2 * (BM + BN) * ROWB;
-    constexpr int epi = BM * (BN + 4) * 4;
-    return stage2 > epi ? stage2 : epi;
+// =====================================================================================================
+// Patch-staged 3x3 stride-1 convolution.
+//
+// The generic kernel above re-reads every input pixel once per tap (9x) and every weight tile once
+// per row tile; on the big layers that L2->LDS traffic (~25 TB/s aggregate, measured by ablation)
+// costs as much time as the MFMAs.  Here a workgroup owns a 2-D tile of TH x TW output pixels of ONE
+// image (256 pixels) and stages, per 64-channel chunk, the (TH+2) x (TW+2) input PATCH (halo
+// included, zero outside the image) in LDS exactly once; all 9 taps read their A fragments from that
+// patch at a shifted pixel index, so activation traffic drops ~8x and only the weight tiles (16 KB per
+// tap for BN=128) stream through a STAGES-deep ring.  8 waves (4 x 2), wave tile 64 x (BN/2),
+// one barrier per tap, counted vmcnt, patch double-buffered across channel chunks.
+// LDS patch image: one 128-B row per patch pixel, 16-B chunk c of pixel q at c ^ ((q>>1)&7) -- the
+// ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
+template <int TH, int TW, int BN, int STAGES>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
+    constexpr int BM = TH * TW;
+    constexpr int NW = 8, WM = 4, WN = 2, NT = 512;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
+    constexpr int PW = TW + 2, PH = TH + 2, NP = PH * PW;
+    constexpr int NP_PAD = (NP + 63) / 64 * 64;
+    constexpr int P_INSTR = NP_PAD / 64;               // patch DMA instructions per wave per chunk (8 pixels each)
+    constexpr int PATCH_BYTES = NP_PAD * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int B_INSTR = BN / 8 / NW;               // weight DMA instructions per wave per tap
+    constexpr int CLD = BN + 4;
+    static_assert(BM == 256 && MI == 2 && (NI == 1 || NI == 2) && B_INSTR >= 1, "shape");
+    static_assert(STAGES >= 2 && (STAGES - 2) * B_INSTR + P_INSTR < 64, "vmcnt range");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch0 = smem;
+    char* bring = smem + 2 * PATCH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.y;
+    const int lrow = lane >> 3, lpos = lane & 7;
+
+    // ---- tile decode: n fastest, then x, y, image ----
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
+    const int tsp = tile / p.ntn, tn = tile - tsp * p.ntn;
+    const int txi = tsp % tiles_x;
+    const int tyi = (tsp / tiles_x) % tiles_y;
+    const int img = tsp / (tiles_x * tiles_y);
+    const int y0 = tyi * TH, x0 = txi * TW, n0 = tn * BN;
+
+    const uint16_t* xg = p.x + (size_t)g * p.Cin;
+    const int Ktot = 9 * p.Cin;
+    const uint16_t* wg = p.w + (size_t)g * p.Cout * Ktot;
+    const int nchunks = p.Cin >> 6;
+    const int KT = nchunks * 9;
+
+    // ---- patch gather addresses (fixed per tile; + 64*chunk per channel chunk) ----
+    long pa_off[P_INSTR];      // element offset, or -1 => zero page
+    int pa_zoff[P_INSTR];
+#pragma unroll
+    for (int j = 0; j < P_INSTR; ++j) {
+        const int q = (wave + NW * j) * 8 + lrow;              // patch pixel index
+        const int chunk = lpos ^ ((q >> 1) & 7);
+        pa_zoff[j] = chunk * 8;
+        const int py = q / PW, px = q - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = (q < NP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        pa_off[j] = ok ? (((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8 : -1;
+    }
+    auto issue_patch = [&](int cc, int buf) {
+        char* dst = patch0 + buf * PATCH_BYTES;
+#pragma unroll
+        for (int j = 0; j < P_INSTR; ++j) {
+            const uint16_t* src = pa_off[j] >= 0 ? xg + (pa_off[j] + cc * 64) : p.zeros + pa_zoff[j];
+            __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(dst + (wave + NW * j) * 1024), 16, 0, 0);
+        }
+    };
+    // ---- weight tile addresses ----
+    const uint16_t* b_src[B_INSTR];
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+        const int n = (wave + NW * j) * 8 + lrow;
+        b_src[j] = wg + (size_t)(n0 + n) * Ktot + (lpos ^ ((n >> 1) & 7)) * 8;
+    }
+    int st_tap = 0, st_cc = 0;                                  // cursor of the next weight tile to issue
+    auto issue_b = [&](int buf) {
+        char* dst = bring + buf * B_BYTES;
+        const int koff = st_tap * p.Cin + st_cc * 64;
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j)
+            __builtin_amdgcn_global_load_lds(W2C_GPTR(b_src[j] + koff), W2C_LPTR(dst + (wave + NW * j) * 1024), 16, 0, 0);
+        if (++st_tap == 9) { st_tap = 0; ++st_cc; }
+    };
+
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int pp0[MI];                                                // patch pixel of this lane's row at tap (0,0)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int tp = wm * WTM + i * 32 + l31;
+        pp0[i] = (tp / TW) * PW + (tp % TW);
+    }
+    const int bswz = (l31 >> 1) & 7;
+
+    auto compute = [&](const char* patch, const char* Bs, int dk) {
+        bf16x8_t a[4][MI], b[4][NI];
+        const char* arow[MI];
+        int aswz[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int pp = pp0[i] + dk;
+            arow[i] = patch + pp * 128;
+            aswz[i] = (pp >> 1) & 7;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a[kk][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + (((kk * 2 + lhi) ^ aswz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                b[kk][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WTN + j * 32 + l31) * 128 +
+                                                              (((kk * 2 + lhi) ^ bswz) << 4));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- pipeline: patch(cc+1) prefetched at tap 0 of chunk cc; weight tiles STAGES-1 ahead ----
+    issue_patch(0, 0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
+    int rd = 0, wr = STAGES - 1, t = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const char* patch = patch0 + (cc & 1) * PATCH_BYTES;
+        const bool more = cc + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            // wait until weight tile t (and everything older, incl. this chunk's patch) has landed.
+            // Younger loads allowed in flight: STAGES-2 weight tiles, plus patch(cc+1) while it is
+            // younger than tile t (it was issued right after tile t0+STAGES-1 at tap 0).
+            if (t + STAGES - 2 < KT) {
+                if (more && tap >= 1 && tap <= STAGES - 1) wait_vmcnt<(STAGES - 2) * B_INSTR + P_INSTR>();
+                else wait_vmcnt<(STAGES - 2) * B_INSTR>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (t + STAGES - 1 < KT) issue_b(wr);
+            if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
+            compute(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3));
+            rd = (rd + 1 == STAGES) ? 0 : rd + 1;
+            wr = (wr + 1 == STAGES) ? 0 : wr + 1;
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue (same contract as the generic kernel; tile row r -> pixel (y0 + r/TW, x0 + r%TW)) ----
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int nl = wn * WTN + j * 32 + l31;
+        const float sc = p.scale[g * p.Cout + n0 + nl];
+        const float sh = p.shift[g * p.Cout + n0 + nl];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                Cs[ml * CLD + nl] = acc[i][j][e] * sc + sh;
+            }
+    }
+    __syncthreads();
+    constexpr int CG = BN / 8;
+    constexpr int PASSES = BM * CG / NT;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = ps * NT + tid;
+        const int r = idx / CG, cg = idx - r * CG;
+        const int oy = y0 + r / TW, ox = x0 + r % TW;
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const size_t off = (((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
+        if (p.res) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(p.res + off);
+            const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFFu));
+                v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.y_f32) {
+            float* yo = reinterpret_cast<float*>(p.y) + off;
+            *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+        } else {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + off) = o;
+        }
+    }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int TH, int TW, int BN, int STAGES>
+int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
+    if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
+        return W2C_E_ARG;
+    a.ntm = a.M * (a.H / TH) * (a.W / TW);
+    a.ntn = a.Cout / BN;
+    constexpr int NP_PAD = ((TH + 2) * (TW + 2) + 63) / 64 * 64;
+    constexpr int ring = 2 * NP_PAD * 128 + STAGES * BN * 128;
+    constexpr int epi = TH * TW * (BN + 4) * 4;
+    constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static unsigned long long attr_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_mask |= 1ull << (dev & 63);
+    }
+    dim3 grid(a.ntm * a.ntn, groups);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, STAGES>), grid, dim3(512), lds, s, a);
+    return w2c_launch_status();
+}
+
+template <int BM, int BN, int BK, int STAGES>
+constexpr int conv_lds_bytes() {
+    constexpr int ring = STAGES * (BM + BN) * BK * 2;
+    constexpr int epi = BM * (BN + 4) * 4;
+    return ring > epi ? ring : epi;
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int STAGES>
 int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
+    if (a.Cin % BK != 0 || a.Cout % BN != 0) return W2C_E_ARG;
+    a.cin_tiles = a.Cin / BK;
+    a.ktiles = a.ks * a.ks * a.cin_tiles;
     a.ntm = (a.rows + BM - 1) / BM;
     a.ntn = a.Cout / BN;
-    constexpr int lds = conv_lds_bytes<BM, BN, WM, WN>();
+    constexpr int lds = conv_lds_bytes<BM, BN, BK, STAGES>();
+    static_assert(lds <= 160 * 1024, "LDS");
     // dynamic LDS above 64 KiB needs the attribute once per device; keep a per-device bit.
     static unsigned long long attr_mask = 0;   // benign race: every thread writes the same attribute
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
+}
+
+// Variant table (index = `variant` of w2c_conv_igemm_bf16_variant; tools/bench_conv.py sweeps it).
+int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
+    switch (variant) {
+        case 0: return launch_conv<128, 128, 2, 2, 64, 2>(a, groups, s);   // r01 baseline structure
+        case 1: return launch_conv<128, 128, 2, 2, 32, 4>(a, groups, s);
+        case 2: return launch_conv<128, 128, 2, 2, 64, 3>(a, groups, s);
+        case 3: return launch_conv<128, 64, 2, 2, 64, 2>(a, groups, s);
+        case 4: return launch_conv<128, 64, 2, 2, 64, 3>(a, groups, s);
+        case 5: return launch_conv<128, 64, 2, 2, 32, 4>(a, groups, s);
+        case 6: return launch_conv<64, 64, 2, 2, 64, 2>(a, groups, s);
+        case 7: return launch_conv<64, 64, 2, 2, 64, 4>(a, groups, s);
+        case 8: return launch_conv<128, 32, 4, 1, 64, 2>(a, groups, s);
+        case 9: return launch_conv<128, 32, 4, 1, 64, 4>(a, groups, s);
+        case 10: return launch_conv<256, 128, 4, 2, 64, 3>(a, groups, s);  // 8 waves
+        case 11: return launch_conv<256, 128, 4, 2, 32, 4>(a, groups, s);  // 8 waves
+        case 12: return launch_conv<128, 128, 2, 2, 32, 3>(a, groups, s);
+        case 13: return launch_conv<64, 64, 2, 2, 64, 3>(a, groups, s);
+        case 14: return launch_conv<128, 64, 2, 2, 64, 4>(a, groups, s);
+        case 15: return launch_conv<256, 64, 4, 1, 64, 3>(a, groups, s);   // 4 waves, 64x64 wave tile
+        // patch-staged 3x3 stride-1 kernels (TH x TW pixel tile, BN, weight-ring stages)
+        case 20: return launch_patch<8, 32, 128, 3>(a, groups, s);
+        case 21: return launch_patch<8, 32, 128, 2>(a, groups, s);
+        case 22: return launch_patch<8, 32, 64, 3>(a, groups, s);
+        case 23: return launch_patch<16, 16, 128, 3>(a, groups, s);
+        case 24: return launch_patch<16, 16, 64, 3>(a, groups, s);
+        case 25: return launch_patch<8, 32, 64, 4>(a, groups, s);
+        case 26: return launch_patch<16, 16, 128, 2>(a, groups, s);
+        default: return W2C_E_ARG;
+    }
+}
+
+// Per-layer kernel choice, from the per-layer sweeps of tools/bench_conv.py on MI355X
+// (profiles/r01_b_conv_variant_sweep.txt).  Stride-1 3x3 convs with >= 128 input channels go to the
+// patch-staged kernel when it can put >= 128 workgroups of 256 pixels on the chip; everything else
+// (stride 2, 1x1, 64-channel layer1, tiny tail layers) to the generic implicit GEMM, whose tile is
+// chosen to keep >= ~2 workgroups per CU.
+int pick_variant(const ConvArgs& a, int groups) {
+    const long rows = a.rows;
+    const int Cout = a.Cout;
+    if (a.ks == 3 && a.stride == 1 && a.Cin >= 128 && a.H % 16 == 0 && a.W % 16 == 0) {
+        const long tiles = (long)a.M * (a.H / 16) * (a.W / 16) * groups;
+        const long c128 = (Cout % 128 == 0) ? tiles * (Cout / 128) : 0;
+        const long c64 = (Cout % 64 == 0) ? tiles * (Cout / 64) : 0;
+        if (c128 >= 512) return 26;
+        if (c64 >= 512) return 24;
+        if (c128 >= 128) return 26;
+        if (c64 >= 128) return 24;
+    }
+    if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return 0;
+    if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
+    if (Cout % 64 == 0) return 6;
+    return 8;
+}
+
+int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+              const uint16_t* w, int Cout, int ksize, int stride, int groups,
+              const float* scale, const float* shift, const uint16_t* residual, int relu,
+              void* y, int y_cstride, int y_is_f32, const void* zero_page) {
+    if (!x || !w || !scale || !shift || !y || !zero_page) return W2C_E_ARG;
+    if (M <= 0 || H <= 0 || W <= 0 || groups <= 0) return W2C_E_ARG;
+    if (Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 32) != 0) return W2C_E_ARG;
+    if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return W2C_E_ARG;
+    if (x_cstride < groups * Cin || y_cstride < groups * Cout) return W2C_E_ARG;
+    if ((x_cstride % 8) != 0 || (y_cstride % 8) != 0) return W2C_E_ARG;   // 16-byte vector access
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.zeros = reinterpret_cast<const uint16_t*>(zero_page);
+    a.M = M; a.H = H; a.W = W; a.Cin = Cin; a.xcs = x_cstride;
+    a.ks = ksize; a.stride = stride; a.pad = ksize == 3 ? 1 : 0;
+    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;
+    a.rows = M * a.Ho * a.Wo;
+    return W2C_OK;
 }
 
 }  // namespace
@@ -273,28 +620,24 @@ extern "C" int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int C
                                    void* y, int y_cstride, int y_is_f32,
                                    const void* zero_page, w2c_stream_t stream) {
     w2c_clear_error();
-    if (!x || !w || !scale || !shift || !y || !zero_page) return W2C_E_ARG;
-    if (M <= 0 || H <= 0 || W <= 0 || groups <= 0) return W2C_E_ARG;
-    if (Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 32) != 0) return W2C_E_ARG;
-    if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return W2C_E_ARG;
-    if (x_cstride < groups * Cin || y_cstride < groups * Cout) return W2C_E_ARG;
-    if ((x_cstride % 8) != 0 || (y_cstride % 8) != 0) return W2C_E_ARG;   // 16-byte vector access
     ConvArgs a;
-    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-    a.zeros = reinterpret_cast<const uint16_t*>(zero_page);
-    a.M = M; a.H = H; a.W = W; a.Cin = Cin; a.xcs = x_cstride;
-    a.ks = ksize; a.stride = stride; a.pad = ksize == 3 ? 1 : 0;
-    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
-    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
-    a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;
-    a.rows = M * a.Ho * a.Wo;
-    a.cin_tiles = Cin / 64;
-    a.ktiles = ksize * ksize * a.cin_tiles;
+    int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
+                       y, y_cstride, y_is_f32, zero_page);
+    if (rc != W2C_OK) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // Tile choice: fill >= ~2 workgroups per CU (256 CUs) where the layer allows it.
-    const long rows = a.rows;
-    if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return launch_conv<128, 128, 2, 2>(a, groups, s);
-    if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return launch_conv<128, 64, 2, 2>(a, groups, s);
-    if (Cout % 64 == 0) return launch_conv<64, 64, 2, 2>(a, groups, s);
-    return launch_conv<128, 32, 4, 1>(a, groups, s);
+    return launch_variant(pick_variant(a, groups), a, groups, s);
+}
+
+extern "C" int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                           const uint16_t* w, int Cout, int ksize, int stride, int groups,
+                                           const float* scale, const float* shift,
+                                           const uint16_t* residual, int relu,
+                                           void* y, int y_cstride, int y_is_f32,
+                                           const void* zero_page, int variant, w2c_stream_t stream) {
+    w2c_clear_error();
+    ConvArgs a;
+    int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
+                       y, y_cstride, y_is_f32, zero_page);
+    if (rc != W2C_OK) return rc;
+    return launch_variant(variant, a, groups, reinterpret_cast<hipStream_t>(stream));
 }

@@ -105,7 +105,7 @@ def maxpool3x3s2(x, out=None):
 
 
 def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
-               out=None, out_f32=False, out_cstride=None):
+               out=None, out_f32=False, out_cstride=None, variant=None):
     """x: bf16 NHWC [M,H,W,xcs]; the conv reads channels [x_ch_off + g*cin, ...).  Returns/accepts
     out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32)."""
     dev = _need_gpu(x, w_packed, scale, shift, residual, out)
@@ -128,10 +128,17 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
     with torch.cuda.device(dev):
-        check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
-                                                _p(scale), _p(shift), _p(residual), 1 if relu else 0,
-                                                _p(out), out_cstride, 1 if out_f32 else 0,
-                                                _p(zero_page(dev)), _stream(dev)), "w2c_conv_igemm_bf16")
+        if variant is None:
+            check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
+                                                    _p(scale), _p(shift), _p(residual), 1 if relu else 0,
+                                                    _p(out), out_cstride, 1 if out_f32 else 0,
+                                                    _p(zero_page(dev)), _stream(dev)), "w2c_conv_igemm_bf16")
+        else:
+            check(_native.lib().w2c_conv_igemm_bf16_variant(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride,
+                                                            groups, _p(scale), _p(shift), _p(residual),
+                                                            1 if relu else 0, _p(out), out_cstride,
+                                                            1 if out_f32 else 0, _p(zero_page(dev)), int(variant),
+                                                            _stream(dev)), "w2c_conv_igemm_bf16_variant(%d)" % variant)
     if timer is not None:
         ev1.record(torch.cuda.current_stream(dev))
         flops = 2.0 * M * Ho * Wo * cout * (ksize * ksize * cin) * groups

@@ -114,6 +114,48 @@ def test_conv_igemm_matches_fp32_conv(case):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
 
 
+VARIANT_CASES = [
+    # variant, M, H, W, Cin, Cout, ks, stride, groups, residual      (see the table in csrc/conv_igemm.hip)
+    (1, 1, 16, 16, 64, 128, 3, 1, 1, False), (2, 1, 16, 16, 128, 128, 3, 2, 1, True), (4, 2, 9, 7, 64, 64, 3, 1, 2, True),
+    (5, 1, 16, 16, 64, 64, 1, 1, 1, False), (7, 3, 5, 5, 128, 64, 3, 1, 1, False), (9, 1, 8, 8, 256, 32, 3, 1, 1, False),
+    (10, 2, 16, 16, 64, 128, 3, 1, 2, True), (11, 1, 16, 20, 64, 128, 3, 1, 1, False), (12, 1, 12, 12, 64, 128, 3, 1, 1, True),
+    (13, 1, 8, 8, 256, 64, 3, 2, 1, False), (14, 2, 10, 10, 128, 64, 3, 1, 1, False), (15, 1, 16, 16, 64, 64, 3, 1, 1, True),
+    # patch-staged kernels: halo at every image border, 2 channel chunks and more, both groups
+    (20, 2, 8, 32, 128, 128, 3, 1, 2, True), (21, 1, 16, 64, 64, 128, 3, 1, 1, False), (22, 2, 8, 32, 256, 64, 3, 1, 1, True),
+    (23, 3, 16, 16, 128, 256, 3, 1, 2, True), (24, 1, 32, 16, 192, 64, 3, 1, 1, False), (25, 1, 8, 64, 64, 64, 3, 1, 2, True),
+    (26, 2, 16, 32, 512, 128, 3, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=["v%d" % c[0] for c in VARIANT_CASES])
+def test_conv_variants_match_fp32_conv(case):
+    """Every tile/pipeline variant (generic ring depths, 8-wave tiles, patch-staged) against fp32."""
+    from multiagentperception_amd import ops
+    variant, M, H, W, cin, cout, ks, stride, G, use_res = case
+    gen = torch.Generator().manual_seed(1000 + variant)
+    pad = 1 if ks == 3 else 0
+    xs = [_rand(gen, M, cin, H, W) for _ in range(G)]
+    ws = [_rand(gen, cout, cin, ks, ks, scale=(2.0 / (cin * ks * ks)) ** 0.5) for _ in range(G)]
+    scale = torch.rand(G * cout, generator=gen) + 0.5
+    shift = torch.randn(G * cout, generator=gen) * 0.1
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    ress = [_rand(gen, M, cout, Ho, Wo) for _ in range(G)] if use_res else None
+    x_dev = torch.cat([x.permute(0, 2, 3, 1) for x in xs], 3).to(BF16).contiguous().to(_dev())
+    w_dev = torch.stack([w.permute(0, 2, 3, 1).reshape(cout, -1).to(BF16) for w in ws], 0).contiguous().to(_dev())
+    res_dev = torch.cat([r.permute(0, 2, 3, 1) for r in ress], 3).to(BF16).contiguous().to(_dev()) if use_res else None
+    y = ops.conv_igemm(x_dev, 0, cin, w_dev, cout, ks, stride, G, scale.to(_dev()), shift.to(_dev()),
+                       residual=res_dev, relu=True, out_f32=True, variant=variant)
+    torch.cuda.synchronize()
+    for g in range(G):
+        ref = F.conv2d(xs[g], ws[g], None, stride=stride, padding=pad)
+        ref = ref * scale[g * cout:(g + 1) * cout].view(1, -1, 1, 1) + shift[g * cout:(g + 1) * cout].view(1, -1, 1, 1)
+        if use_res:
+            ref = ref + ress[g]
+        ref = F.relu(ref)
+        np.testing.assert_allclose(_to_nchw(y, g * cout, cout).numpy(), ref.numpy(), atol=2e-4, rtol=2e-4)
+
+
 @pytest.mark.parametrize("cout,B,N,H,W", [(64, 2, 1, 64, 64), (128, 2, 3, 64, 128), (128, 1, 2, 128, 128)])
 def test_stem_matches_fp32_conv7x7_bn_relu(cout, B, N, H, W):
     from multiagentperception_amd import ops
