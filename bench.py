@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="softmax", choices=["softmax", "argmax_test", "activated"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +119,7 @@ def main():
     model = get_model(build_cfg(N, S), 11)
     filler.apply_to_module(model)
     model = model.to(dev).eval()
+    model.use_hip_graph = not args.no_graph
     frames = filler.synthetic_frames(B, n_loc, S, S, 1234 + 2 + rank)          # cfg 2 seed + rank
     x = torch.from_numpy(frames).to(dev)
     fwd = AgentParallelForward(model)
@@ -149,12 +151,14 @@ def main():
 
     # ---- roofline attribution pass (dominant kernel), outside the timed region -------------------
     timer = ops.KernelTimer()
+    model.use_hip_graph = False                      # per-launch events need eager launches
     ops.set_conv_timer(timer)
     reps = 3
     for _ in range(reps):
         step()
     torch.cuda.synchronize(dev)
     ops.set_conv_timer(None)
+    model.use_hip_graph = not args.no_graph
     conv_ms, conv_fl, launches, per_shape = timer.summary()
     conv_ms /= reps
     conv_fl /= reps
@@ -175,7 +179,8 @@ def main():
                   config=dict(workload="mrms-when2com MIMOcom forward (eval, inference=%s), %d agents/GPU x B=%d x %dx%d, "
                                        "agent-parallel K/V all-gather" % (args.mode, n_loc, B, S, S),
                               agents_total=N, global_batch=B, frames_per_s=round(B * args.steps / elapsed, 2),
-                              parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)"),
+                              parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
+                              launch="hip-graph replay" if (model.use_hip_graph and world == 1) else "eager"),
                   roofline=roofline)
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, single GPU only) ---------------------

@@ -53,6 +53,12 @@ int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int W,
                              const uint16_t* w, const float* scale, const float* shift, int Cout,
                              uint16_t* y, w2c_stream_t stream);
 
+/* ---- K1 + K1b fused: the same stem followed by maxpool 3x3 s2 p1 (backbone.py:66), the half-resolution
+ * conv map never leaves the chip.  y : bf16 NHWC [N*B, H/4, W/4, Cout].  Same argument rules as above. */
+int w2c_stem_conv7x7_bn_relu_maxpool(const float* x, int B, int N, int H, int W,
+                                     const uint16_t* w, const float* scale, const float* shift, int Cout,
+                                     uint16_t* y, w2c_stream_t stream);
+
 /* ---- K1b: maxpool 3x3 s2 p1 (backbone.py:66 via resnet.maxpool), bf16 NHWC.
  * x [M, H, W, C] -> y [M, H/2, W/2, C]; C multiple of 8. */
 int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, w2c_stream_t stream);
@@ -93,6 +99,14 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
  * w : f32 [O, K] row-major; b : f32 [O]; y : f32 [M, O].  K multiple of 4, M <= 64 per call. */
 int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M, int K,
                    const float* w, const float* b, int O, int relu, float* y, w2c_stream_t stream);
+
+/* ---- K5b: the two small layers of a head in one launch: out = W2 relu(W1 h0 + b1) + b2
+ * (fc.2, ReLU, fc.4 of km_generator / linear, agent.py:152-155).
+ * h0 : f32 [M, >=K1] row stride h0_stride (the ReLU'd fc.0 output); w1t : f32 [K1, H1] (K-major,
+ * i.e. fc.2.weight transposed), b1 [H1]; w2t : f32 [H1, O] (fc.4.weight transposed), b2 [O];
+ * out : f32 [M, O].  H1 <= 256. */
+int w2c_head_tail_f32(const float* h0, int h0_stride, int M, int K1, const float* w1t, const float* b1, int H1,
+                      const float* w2t, const float* b2, int O, float* out, w2c_stream_t stream);
 
 /* ---- K6: communication graph.  MIMOGeneralDotProductAttention scores +
  * softmax over keys (agent.py:256,268,274), the +0.001*I tie-break

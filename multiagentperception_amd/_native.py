@@ -21,11 +21,13 @@ SIGNATURES = {
     "w2c_last_error_string": [],
     "w2c_device_arch": [_c.c_char_p, _i],
     "w2c_stem_conv7x7_bn_relu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "w2c_stem_conv7x7_bn_relu_maxpool": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "w2c_maxpool3x3s2": [_vp, _i, _i, _i, _i, _vp, _vp],
     "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
     "w2c_conv_igemm_bf16_variant": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
                                     _vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
+    "w2c_head_tail_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp],
     "w2c_comm_graph": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "w2c_fuse_values": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -129,6 +129,57 @@ __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restric
     }
 }
 
+// Head tail: out = W2 relu(W1 h0 + b1) + b2 for one head (km_generator / linear fc.2, fc.4;
+// agent.py:152-155).  One workgroup per image row; h0 / h1 live in LDS; weights are packed K-MAJOR
+// ([K][O]) so consecutive threads read consecutive outputs of one k (coalesced, L2-resident).
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ h0, int h0_stride, int K1,
+                                                        const float* __restrict__ w1t, const float* __restrict__ b1, int H1,
+                                                        const float* __restrict__ w2t, const float* __restrict__ b2, int O,
+                                                        float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_h0 = reinterpret_cast<float*>(smem);          // [K1]
+    float* s_h1 = s_h0 + K1;                               // [H1]
+    float* s_part = s_h1 + H1;                             // [256]
+    const int m = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < K1; k += 256) s_h0[k] = h0[(size_t)m * h0_stride + k];
+    __syncthreads();
+    // layer 1: thread = (output j, K-partition)
+    const int parts = 256 / H1;                            // H1 <= 256
+    {
+        const int j = tid % H1, part = tid / H1;
+        float a0 = 0.f, a1 = 0.f;
+        if (part < parts) {
+            int k = part;
+            for (; k + parts < K1; k += 2 * parts) {
+                a0 = fmaf(w1t[(size_t)k * H1 + j], s_h0[k], a0);
+                a1 = fmaf(w1t[(size_t)(k + parts) * H1 + j], s_h0[k + parts], a1);
+            }
+            for (; k < K1; k += parts) a0 = fmaf(w1t[(size_t)k * H1 + j], s_h0[k], a0);
+        }
+        s_part[tid] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < H1) {
+        float v = b1[tid];
+        for (int pp = 0; pp < parts; ++pp) v += s_part[pp * H1 + tid];
+        s_h1[tid] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    // layer 2: thread = output o (strided), K = H1
+    for (int o = tid; o < O; o += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = 0;
+        for (; k + 3 < H1; k += 4) {
+            a0 = fmaf(w2t[(size_t)k * O + o], s_h1[k], a0);
+            a1 = fmaf(w2t[(size_t)(k + 1) * O + o], s_h1[k + 1], a1);
+            a2 = fmaf(w2t[(size_t)(k + 2) * O + o], s_h1[k + 2], a2);
+            a3 = fmaf(w2t[(size_t)(k + 3) * O + o], s_h1[k + 3], a3);
+        }
+        for (; k < H1; ++k) a0 = fmaf(w2t[(size_t)k * O + o], s_h1[k], a0);
+        out[(size_t)m * O + o] = (a0 + a1) + (a2 + a3) + b2[o];
+    }
+}
+
 // ---------------------------------------------------------------- K6: communication graph
 // score[k][q] = key[k] . (Wq query[q] + bq) = (Wq^T key[k]) . query[q] + key[k] . bq
 // so only T[k] = Wq^T key[k] (Dq values) and t0[k] = key[k].bq are formed: N*Dk*Dq MACs and no
@@ -310,6 +361,17 @@ extern "C" int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M,
         hipLaunchKernelGGL((linear_kernel<16, true>), grid, dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
     else
         hipLaunchKernelGGL((linear_kernel<16, false>), grid, dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_head_tail_f32(const float* h0, int h0_stride, int M, int K1, const float* w1t, const float* b1, int H1,
+                                 const float* w2t, const float* b2, int O, float* out, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!h0 || !w1t || !b1 || !w2t || !b2 || !out || M <= 0 || K1 <= 0 || H1 <= 0 || H1 > 256 || O <= 0) return W2C_E_ARG;
+    if (h0_stride < K1) return W2C_E_ARG;
+    const size_t lds = (size_t)(K1 + H1 + 256) * 4;
+    hipLaunchKernelGGL(head_tail_kernel, dim3(M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       h0, h0_stride, K1, w1t, b1, H1, w2t, b2, O, out);
     return w2c_launch_status();
 }
 

@@ -59,22 +59,40 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                 wf[ky][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ky * 32 + (ks * 2 + lhi) * 8);
     }
 
-    for (int ox0 = 0; ox0 < Wo; ox0 += 32) {
-        // ---- input patch: f32 NCHW planes -> bf16 [row][col][4] in LDS (zero outside the image) ----
+    // ---- input patch staging, software-pipelined across x tiles: every thread owns FILL patch pixels;
+    // the 3*FILL f32 loads of tile i+1 are issued before the MFMAs of tile i and consumed after them,
+    // so the HBM round trip hides behind the matrix work instead of stalling each tile six times.
+    constexpr int FILL = (PATCH_ROWS * PATCH_COLS + 255) / 256;         // 6
+    float pv[FILL][3];
+    auto load_patch = [&](int ox0) {
         const int iy_base = 2 * oy0 - 3, ix_base = 2 * ox0 - 3;
-        for (int pidx = tid; pidx < PATCH_ROWS * PATCH_COLS; pidx += 256) {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int pidx = tid + f * 256;
             const int r = pidx / PATCH_COLS, c = pidx - r * PATCH_COLS;
             const int iy = iy_base + r, ix = ix_base + c;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const size_t o = (size_t)iy * W + ix;
-                v0 = xin[o];
-                v1 = xin[o + (size_t)H * W];
-                v2 = xin[o + 2 * (size_t)H * W];
-            }
-            patch[pidx] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f));
+            const bool ok = (pidx < PATCH_ROWS * PATCH_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+            const size_t o = ok ? (size_t)iy * W + ix : 0;              // clamp: always a valid address
+            const float a0 = xin[o], a1 = xin[o + (size_t)H * W], a2 = xin[o + 2 * (size_t)H * W];
+            pv[f][0] = ok ? a0 : 0.f;
+            pv[f][1] = ok ? a1 : 0.f;
+            pv[f][2] = ok ? a2 : 0.f;
         }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int pidx = tid + f * 256;
+            if (pidx < PATCH_ROWS * PATCH_COLS)
+                patch[pidx] = make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f));
+        }
+    };
+
+    load_patch(0);
+    for (int ox0 = 0; ox0 < Wo; ox0 += 32) {
+        store_patch();                                   // (previous tile's MFMA reads are behind a barrier)
         __syncthreads();
+        if (ox0 + 32 < Wo) load_patch(ox0 + 32);         // in flight during this tile's MFMAs
 
         f32x16_t acc[MT];
 #pragma unroll
@@ -125,6 +143,170 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         // next iteration's patch fill is ordered after this iteration's MFMA reads by the
         // barrier above; its staging writes are ordered after this read-out by the barrier
         // that follows the patch fill.
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused stem: conv 7x7/2 + BN + ReLU + maxpool 3x3/2 p1 (backbone.py:65-66,76-80) in one kernel.
+// The unfused pair writes the 64(x2)-channel half-resolution map to HBM and reads it straight
+// back (cfg 2: 335 MB each way); here a workgroup (8 waves) owns a band of 8 conv rows, walks it in
+// 32-column steps and per step computes a 9 x 32 conv tile (the row above the band is recomputed:
+// +12.5 % MFMA work; the column left of the step is carried in LDS from the previous step), stages
+// it as bf16 in LDS, pools 3x3/2 there and writes only the pooled 4 x 16 pixels.  ReLU outputs are
+// >= 0 and every pooling window holds at least one in-image pixel, so out-of-image conv pixels are
+// staged as 0 instead of -inf (identical maxima).
+constexpr int FP_ROWS = 23;        // input rows for 9 conv rows: 2*8 + 7
+constexpr int FP_COLS = 72;
+constexpr int FP_BYTES = FP_ROWS * FP_COLS * 8;
+
+template <int COUT>
+__global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict__ x, int B, int N, int H, int W,
+                                                        const uint16_t* __restrict__ wpk,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        uint16_t* __restrict__ y) {
+    constexpr int CT = COUT / 32;           // channel tiles
+    constexpr int NPART = 8 / CT;           // pixel-tile partitions across waves (2 or 4)
+    constexpr int MT_MAX = (9 + NPART - 1) / NPART + (NPART == 2 ? 0 : 0);   // 5 or 3
+    constexpr int ROWBYTES = COUT * 2;      // staged bytes per conv pixel
+    constexpr int CHUNKS = ROWBYTES / 16;
+    constexpr int SCOLS = 33;               // staged columns: [carry | 32 new]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* patch = reinterpret_cast<uint2*>(smem);
+    char* stg = smem + FP_BYTES;            // [9][33][COUT] bf16, 16-B chunks swizzled by (col & (CHUNKS-1))
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave % CT, part = wave / CT;
+    const int mt_lo = (9 * part) / NPART, mt_hi = (9 * (part + 1)) / NPART;      // this wave's conv rows [mt_lo, mt_hi)
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1, Hp = H >> 2, Wp = W >> 2;
+    const int img = blockIdx.y;
+    const int agent = img / B, b = img - agent * B;
+    const int oy0 = blockIdx.x * 8;
+    const float* xin = x + ((size_t)b * 3 * N + 3 * agent) * H * W;
+
+    bf16x8_t wf[7][2];
+    {
+        const uint16_t* wrow = wpk + (size_t)(ct * 32 + l31) * 224;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[ky][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ky * 32 + (ks * 2 + lhi) * 8);
+    }
+
+    constexpr int FILL = (FP_ROWS * FP_COLS + 511) / 512;               // 4
+    float pv[FILL][3];
+    auto load_patch = [&](int ox0) {
+        const int iy_base = 2 * oy0 - 5, ix_base = 2 * ox0 - 3;         // conv row oy0-1 needs input row 2*(oy0-1)-3
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int pidx = tid + f * 512;
+            const int r = pidx / FP_COLS, c = pidx - r * FP_COLS;
+            const int iy = iy_base + r, ix = ix_base + c;
+            const bool ok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+            const size_t o = ok ? (size_t)iy * W + ix : 0;
+            const float a0 = xin[o], a1 = xin[o + (size_t)H * W], a2 = xin[o + 2 * (size_t)H * W];
+            pv[f][0] = ok ? a0 : 0.f;
+            pv[f][1] = ok ? a1 : 0.f;
+            pv[f][2] = ok ? a2 : 0.f;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int pidx = tid + f * 512;
+            if (pidx < FP_ROWS * FP_COLS)
+                patch[pidx] = make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f));
+        }
+    };
+    auto stg_addr = [&](int row, int col, int chunk) -> char* {
+        return stg + ((row * SCOLS + col) * CHUNKS + (chunk ^ (col & (CHUNKS - 1)))) * 16;
+    };
+
+    // carry column (conv column -1) of the first step is outside the image: zeros
+    for (int i = tid; i < 9 * CHUNKS; i += 512)
+        *reinterpret_cast<uint4*>(stg_addr(i / CHUNKS, 0, i % CHUNKS)) = make_uint4(0, 0, 0, 0);
+
+    load_patch(0);
+    for (int ox0 = 0; ox0 < Wo; ox0 += 32) {
+        store_patch();
+        __syncthreads();                    // patch visible; previous step's pooling reads + carry copy are done
+        if (ox0 + 32 < Wo) load_patch(ox0 + 32);
+
+        f32x16_t acc[MT_MAX];
+#pragma unroll
+        for (int m = 0; m < MT_MAX; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT_MAX; ++m) {
+            const int mt = mt_lo + m;
+            if (mt < mt_hi) {
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    const uint2* prow = patch + (2 * mt + ky) * FP_COLS + 2 * l31 + 2 * lhi;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(prow + ks * 4);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], pb, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // BN + ReLU -> bf16 -> staging[mt][1 + l31][channels]; conv row oy0-1+mt < 0 is outside the image
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = ct * 32 + 8 * q + 4 * lhi;
+            const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + ch);
+            const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(shift + ch);
+#pragma unroll
+            for (int m = 0; m < MT_MAX; ++m) {
+                const int mt = mt_lo + m;
+                if (mt < mt_hi) {
+                    const bool inimg = (oy0 - 1 + mt) >= 0;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = inimg ? fmaxf(acc[m][4 * q + r] * sc[r] + sh[r], 0.f) : 0.f;
+                    *reinterpret_cast<uint2*>(stg_addr(mt, 1 + l31, ct * 4 + q) + lhi * 8) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+        }
+        __syncthreads();
+        // pool 3x3/2: pooled (pyl, pxl) <- staged rows 2*pyl..2*pyl+2, staged cols 2*pxl..2*pxl+2
+        for (int id = tid; id < 64 * CHUNKS; id += 512) {
+            const int cg = id % CHUNKS, pp = id / CHUNKS;
+            const int pyl = pp >> 4, pxl = pp & 15;
+            float best[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(stg_addr(2 * pyl + dy, 2 * pxl + dx, cg));
+                    const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        best[2 * e] = fmaxf(best[2 * e], bf16_to_f32((uint16_t)(wv[e] & 0xFFFFu)));
+                        best[2 * e + 1] = fmaxf(best[2 * e + 1], bf16_to_f32((uint16_t)(wv[e] >> 16)));
+                    }
+                }
+            uint4 o;
+            o.x = pack_bf16x2(best[0], best[1]); o.y = pack_bf16x2(best[2], best[3]);
+            o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
+            const int py = (oy0 >> 1) + pyl, px = (ox0 >> 1) + pxl;
+            *reinterpret_cast<uint4*>(y + (((size_t)img * Hp + py) * Wp + px) * COUT + cg * 8) = o;
+        }
+        __syncthreads();
+        // carry: staged column 32 (conv column ox0+31) becomes column 0 of the next step
+        for (int i = tid; i < 9 * CHUNKS; i += 512) {
+            const int row = i / CHUNKS, cg = i % CHUNKS;
+            *reinterpret_cast<uint4*>(stg_addr(row, 0, cg)) = *reinterpret_cast<const uint4*>(stg_addr(row, 32, cg));
+        }
+        // (ordered before the next step's staging writes by the barrier after store_patch)
     }
 }
 
@@ -193,6 +375,35 @@ extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (Cout == 128) return launch_stem<128>(x, B, N, H, W, w, scale, shift, y, s);
     if (Cout == 64) return launch_stem<64>(x, B, N, H, W, w, scale, shift, y, s);
+    return W2C_E_ARG;
+}
+
+template <int COUT>
+static int launch_stem_pool(const float* x, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+                     const float* shift, uint16_t* y, hipStream_t s) {
+    constexpr int lds = FP_BYTES + 9 * 33 * COUT * 2;
+    static unsigned long long attr_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_mask |= 1ull << (dev & 63);
+    }
+    dim3 grid((H / 2) / 8, N * B);
+    hipLaunchKernelGGL((stem_pool_kernel<COUT>), grid, dim3(512), lds, s, x, B, N, H, W, w, scale, shift, y);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_stem_conv7x7_bn_relu_maxpool(const float* x, int B, int N, int H, int W,
+                                                const uint16_t* w, const float* scale, const float* shift, int Cout,
+                                                uint16_t* y, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !w || !scale || !shift || !y) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 64) != 0) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (Cout == 128) return launch_stem_pool<128>(x, B, N, H, W, w, scale, shift, y, s);
+    if (Cout == 64) return launch_stem_pool<64>(x, B, N, H, W, w, scale, shift, y, s);
     return W2C_E_ARG;
 }
 

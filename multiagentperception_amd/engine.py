@@ -1,8 +1,7 @@
 """HIP engine for the When2com forward path: packs a module's weights once and drives the kernels.
 
 Path (reference file:line -> kernel):
-  divide_inputs + cat + resnet conv1/bn1/relu   agent.py:1088-1108, backbone.py:76-80 -> w2c_stem_conv7x7_bn_relu
-  maxpool                                        backbone.py:66                         -> w2c_maxpool3x3s2
+  divide_inputs + cat + conv1/bn1/relu/maxpool  agent.py:1088-1108, backbone.py:66,76-80 -> w2c_stem_conv7x7_bn_relu_maxpool
   layer1..4 BasicBlocks, squeezer, policy convs  backbone.py:66-69, agent.py:54,126-132 -> w2c_conv_igemm_bf16
   key / query heads                              agent.py:150-159                        -> w2c_linear_f32
   scores, softmax over keys, mode transforms     agent.py:252-286, 1036-1078, 1164-1167  -> w2c_comm_graph
@@ -110,40 +109,55 @@ class TrunkPlan:
         sq = [e.squeezer.cbr_unit for e in encoders]
         self.squeezer = ConvPlan([s[0] for s in sq], [s[1] for s in sq], relu=True)
 
-    def run(self, x, n_agents):
-        """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/32, W/32, G*feat] (squeezer outputs side by side)."""
-        s0 = ops.stem_conv7x7_bn_relu(x, n_agents, self.stem_w, self.stem_scale, self.stem_shift)
-        p = ops.maxpool3x3s2(s0)
-        del s0
+    def stem(self, x, n_agents, out=None):
+        """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/4, W/4, G*64]: conv1+bn1+relu+maxpool of all trunks, fused
+        (agent-major)."""
+        return ops.stem_conv7x7_bn_relu_maxpool(x, n_agents, self.stem_w, self.stem_scale, self.stem_shift, out=out)
+
+    def after_stem(self, p):
+        """layer1..4 + squeezers on the pooled stem output -> bf16 NHWC [N*B, H/32, W/32, G*feat]."""
         for c1, c2, ds in self.blocks:
             t = c1.run(p)
             idt = p if ds is None else ds.run(p)
             p = c2.run(t, residual=idt)
         return self.squeezer.run(p)
 
+    def run(self, x, n_agents):
+        """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/32, W/32, G*feat] (squeezer outputs side by side)."""
+        return self.after_stem(self.stem(x, n_agents))
+
 
 class HeadPlan:
-    """km_generator / linear: Linear-ReLU-Linear-ReLU-Linear on the NCHW-flattened policy map
-    (agent.py:157-159).  The map arrives NHWC, so fc.0's columns are permuted once instead."""
+    """km_generator / linear heads: Linear-ReLU-Linear-ReLU-Linear on the NCHW-flattened policy map
+    (agent.py:157-159).  The map arrives NHWC, so fc.0's columns are permuted once instead.  All heads'
+    fc.0 run as ONE wide-K launch (weights stacked along the output dim); fc.2+ReLU+fc.4 of each head
+    is one w2c_head_tail_f32 launch (weights packed K-major)."""
 
-    def __init__(self, head, hw):
-        fc = head.fc
-        w0 = fc[0].weight.detach().float()
-        n_feat = w0.shape[1]
-        c = n_feat // hw
-        self.w0 = w0.reshape(w0.shape[0], c, hw).permute(0, 2, 1).reshape(w0.shape[0], n_feat).contiguous()
-        self.b0 = fc[0].bias.detach().float().contiguous()
-        self.w1 = fc[2].weight.detach().float().contiguous()
-        self.b1 = fc[2].bias.detach().float().contiguous()
-        self.w2 = fc[4].weight.detach().float().contiguous()
-        self.b2 = fc[4].bias.detach().float().contiguous()
+    def __init__(self, heads, hw):
+        w0s, b0s = [], []
+        self.tails = []
+        for head in heads:
+            fc = head.fc
+            w0 = fc[0].weight.detach().float()
+            n_feat = w0.shape[1]
+            c = n_feat // hw
+            w0s.append(w0.reshape(w0.shape[0], c, hw).permute(0, 2, 1).reshape(w0.shape[0], n_feat))
+            b0s.append(fc[0].bias.detach().float())
+            self.tails.append((w0.shape[0], fc[2].weight.detach().float().t().contiguous(),
+                               fc[2].bias.detach().float().contiguous(),
+                               fc[4].weight.detach().float().t().contiguous(), fc[4].bias.detach().float().contiguous()))
+        self.w0 = torch.cat(w0s, 0).contiguous()
+        self.b0 = torch.cat(b0s).contiguous()
         self.n_feat = n_feat
 
     def run(self, qk_map):
         M = qk_map.shape[0]
-        y = ops.linear(qk_map, self.w0, self.b0, relu=True, x_stride=self.n_feat, rows=M)
-        y = ops.linear(y, self.w1, self.b1, relu=True)
-        return ops.linear(y, self.w2, self.b2, relu=False)
+        h0 = ops.linear(qk_map, self.w0, self.b0, relu=True, x_stride=self.n_feat, rows=M)     # [M, 256*nheads]
+        outs, col = [], 0
+        for k1, w1t, b1, w2t, b2 in self.tails:
+            outs.append(ops.head_tail(h0, col, k1, w1t, b1, w2t, b2))
+            col += k1
+        return outs
 
 
 class DecoderPlan:
@@ -153,9 +167,12 @@ class DecoderPlan:
         self.c2 = ConvPlan([pred[2]], relu=False, pad_cout_to=32)
         self.n_classes = n_classes
 
-    def run(self, feat):
+    def low_logits(self, feat):
         y = self.c0.run(feat)
-        low = self.c2.run(y, out_f32=True)                  # f32 NHWC [M,h,w,32], channels >= n_classes are 0
+        return self.c2.run(y, out_f32=True)                 # f32 NHWC [M,h,w,32], channels >= n_classes are 0
+
+    def run(self, feat):
+        low = self.low_logits(feat)
         return ops.upsample_bilinear32(low, self.n_classes), low
 
 
@@ -171,13 +188,13 @@ class CommEngine:
         pn = model.query_key_net
         self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
                        for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
-        self.key_head = None        # built lazily: fc.0's column permutation needs the map's h*w
-        self.query_head = None
+        self.heads = None           # built lazily: fc.0's column permutation needs the map's h*w
         self._model_heads = (model.key_net, model.query_net if self.has_query else None)
         self.wq = model.attention_net.linear.weight.detach().float().contiguous()
         self.bq = model.attention_net.linear.bias.detach().float().contiguous()
         self.decoder = DecoderPlan(model.decoder, self.n_classes)
         self.feat = 512
+        self._graphs = {}
 
     def policy_tail(self, sq):
         """policy_net4 conv1..5 + key/query heads on the policy-encoder half of `sq` (agent.py:137-141,
@@ -186,13 +203,10 @@ class CommEngine:
         for c in self.policy[1:]:
             y = c.run(y)
         hw = y.shape[1] * y.shape[2]
-        if self.key_head is None:
-            self.key_head = HeadPlan(self._model_heads[0], hw)
-            if self._model_heads[1] is not None:
-                self.query_head = HeadPlan(self._model_heads[1], hw)
-        keys = self.key_head.run(y)
-        querys = self.query_head.run(y) if self.query_head is not None else None
-        return keys, querys
+        if self.heads is None:
+            self.heads = HeadPlan([h for h in self._model_heads if h is not None], hw)
+        outs = self.heads.run(y)
+        return outs[0], (outs[1] if len(outs) > 1 else None)
 
     def encode(self, x, n_agents):
         """-> sq (bf16 NHWC [n*B,h,w,1024]: V in [0,512), policy-encoder map in [512,1024)),
@@ -201,13 +215,59 @@ class CommEngine:
         keys, querys = self.policy_tail(sq)
         return sq, keys, querys
 
-    def graph_and_decode(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
-        """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decode."""
+    def graph_and_low(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
+        """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decoder convs
+        (everything up to the low-resolution logits)."""
         prob, coef, action, nnz = ops.comm_graph(querys_local, keys_all, self.wq, self.bq, B, N, self.who, mode,
                                                  q_lo=q_lo, q_n=q_n)
         fused = ops.fuse_values(sq_all, self.feat, coef, B, N, q_lo, q_n, append_own=self.who)
-        pred, low = self.decoder.run(fused)
-        return pred, prob, action, nnz, low
+        return self.decoder.low_logits(fused), prob, action, nnz
+
+    def graph_and_decode(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
+        low, prob, action, nnz = self.graph_and_low(sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode)
+        return ops.upsample_bilinear32(low, self.n_classes), prob, action, nnz, low
+
+    # ---- whole single-GPU forward, optionally replayed from a captured HIP graph ------------------
+    def forward_local(self, x, B, N, mode, use_graph=False):
+        """-> pred f32 [N*B,n_cls,H,W] (fresh tensor), prob [B,N,N], action [B,N], nnz [B]."""
+        if not use_graph:
+            sq, keys, querys = self.encode(x, N)
+            pred, prob, action, nnz, _ = self.graph_and_decode(sq, keys, querys, B, N, 0, N, mode)
+            return pred, prob, action, nnz
+        key = (tuple(x.shape), mode)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(x, B, N, mode)
+            self._graphs[key] = entry
+        s0, graph, low, prob, action, nnz = entry
+        self.trunk.stem(x, N, out=s0)                       # eager: reads the caller's tensor
+        graph.replay()                                      # maxpool ... decoder convs (45 launches)
+        pred = ops.upsample_bilinear32(low, self.n_classes)  # eager: writes the caller-owned output
+        return pred, prob.clone(), action.clone(), nnz.clone()
+
+    def _capture(self, x, B, N, mode):
+        """Capture everything between the stem and the final upsample into one HIP graph.  The stem
+        output is the graph's static input buffer (the stem writes straight into it: no copy); the
+        low-resolution logits / prob / action / nnz are its static outputs."""
+        dev = x.device
+
+        def middle(s0):
+            sq = self.trunk.after_stem(s0)
+            keys, querys = self.policy_tail(sq)
+            return self.graph_and_low(sq, keys, querys, B, N, 0, N, mode)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            s0 = self.trunk.stem(x, N)
+            for _ in range(2):                               # warm-up: func attributes, head plans, allocator
+                middle(s0)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            low, prob, action, nnz = middle(s0)
+        return s0, graph, low, prob, action, nnz
 
 
 class SingleEngine:

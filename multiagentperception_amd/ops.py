@@ -94,6 +94,22 @@ def stem_conv7x7_bn_relu(x, n_agents, w_packed, scale, shift, out=None):
     return out
 
 
+def stem_conv7x7_bn_relu_maxpool(x, n_agents, w_packed, scale, shift, out=None):
+    """x f32 [B,3N,H,W] -> bf16 NHWC [N*B, H/4, W/4, Cout]: stem + maxpool 3x3/2 fused."""
+    dev = _need_gpu(x, w_packed, scale, shift, out)
+    B, c3n, H, W = x.shape
+    if c3n != 3 * n_agents or x.dtype != torch.float32:
+        raise W2CError("stem: expected f32 [B, 3*%d, H, W], got %s %s" % (n_agents, tuple(x.shape), x.dtype))
+    cout = scale.numel()
+    if out is None:
+        out = torch.empty((n_agents * B, H // 4, W // 4, cout), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_stem_conv7x7_bn_relu_maxpool(_p(x), B, n_agents, H, W, _p(w_packed), _p(scale),
+                                                             _p(shift), cout, _p(out), _stream(dev)),
+              "w2c_stem_conv7x7_bn_relu_maxpool")
+    return out
+
+
 def maxpool3x3s2(x, out=None):
     dev = _need_gpu(x, out)
     M, H, W, C = x.shape
@@ -159,6 +175,19 @@ def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
         check(_native.lib().w2c_linear_f32(_p(x), 1 if x.dtype == BF16 else 0, x_stride, rows, K, _p(w), _p(b), O,
                                            1 if relu else 0, _p(y), _stream(dev)), "w2c_linear_f32")
     return y
+
+
+def head_tail(h0, col_off, k1, w1t, b1, w2t, b2):
+    """out[M,O] = W2 relu(W1 h0[:, col_off:col_off+k1] + b1) + b2 (weights K-major)."""
+    dev = _need_gpu(h0, w1t, b1, w2t, b2)
+    M, stride = h0.shape
+    H1 = w1t.shape[1]
+    O = w2t.shape[1]
+    out = torch.empty((M, O), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_head_tail_f32(h0.data_ptr() + 4 * col_off, stride, M, k1, _p(w1t), _p(b1), H1, _p(w2t),
+                                              _p(b2), O, _p(out), _stream(dev)), "w2c_head_tail_f32")
+    return out
 
 
 MODE_IDS = {"softmax": 0, "argmax_test": 1, "activated": 2}

@@ -77,6 +77,8 @@ class AgentParallelForward:
         N = model.agent_num
         with torch.no_grad():
             x = inputs_local.contiguous().float()
+            if self.world == 1:
+                return eng.forward_local(x, B, N, inference, use_graph=getattr(model, "use_hip_graph", False))
             sq = eng.trunk.run(x, self.n_loc)                                  # [n_loc*B,h,w,1024]
             v_loc = sq[..., :eng.feat].contiguous() if self.world > 1 else None
             v_all, v_work = exchange_start(v_loc, self.group) if self.world > 1 else (None, None)

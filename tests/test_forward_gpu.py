@@ -151,3 +151,26 @@ def test_evaluate_call_sequence_harness():
     score = evaluate_batches(model, [(images_list, labels_list)], device="cuda:0", inference_mode="softmax")
     assert abs(score["Mean IoU"] - float(g["softmax_miou"])) <= MIOU_TOL
     assert score["bandwidth"] == n - 1
+
+
+def test_hip_graph_replay_equals_eager_bit_for_bit():
+    """W2C_HIP_GRAPH path: the captured middle of the forward must reproduce the eager launches exactly,
+    on the capture input AND on a different input of the same shape (static-buffer plumbing)."""
+    case = CASES[0]
+    model, _ = _build(case)
+    b, n, s = case["batch"], case["agent_num"], case["size"]
+    x1 = torch.from_numpy(filler.synthetic_frames(b, n, s, s, 501)).cuda()
+    x2 = torch.from_numpy(filler.synthetic_frames(b, n, s, s, 502)).cuda()
+    eager = [model(x, training=False, MO_flag=True, inference="activated") for x in (x1, x2)]
+    model.use_hip_graph = True
+    for x, ref in ((x1, eager[0]), (x2, eager[1]), (x1, eager[0])):
+        out = model(x, training=False, MO_flag=True, inference="activated")
+        np.testing.assert_array_equal(out[0].cpu().numpy(), ref[0].cpu().numpy())
+        np.testing.assert_array_equal(out[1].cpu().numpy(), ref[1].cpu().numpy())
+        np.testing.assert_array_equal(out[2].cpu().numpy(), ref[2].cpu().numpy())
+        assert out[3] == ref[3]
+    # outputs are caller-owned: a later forward must not overwrite an earlier result
+    keep = model(x1, training=False, MO_flag=True, inference="activated")
+    snap = keep[1].clone()
+    model(x2, training=False, MO_flag=True, inference="activated")
+    np.testing.assert_array_equal(keep[1].cpu().numpy(), snap.cpu().numpy())

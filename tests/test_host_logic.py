@@ -98,7 +98,7 @@ def test_bn_fold_and_weight_packing_math():
     # head: NHWC-flattened input x permuted fc.0 == NCHW-flattened input x original fc.0
     head = blocks.km_generator(out_size=32, input_feat_sz=256 / 32)      # n_feat = 256*2*2
     filler.apply_to_module(head)
-    hp = engine.HeadPlan(head, hw=4)
+    hp = engine.HeadPlan([head], hw=4)
     fmap = torch.randn(3, 256, 2, 2, generator=gen)
     ref = F.linear(fmap.reshape(3, -1), head.fc[0].weight, head.fc[0].bias)
     got = F.linear(fmap.permute(0, 2, 3, 1).reshape(3, -1), hp.w0, hp.b0)

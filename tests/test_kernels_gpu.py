@@ -179,6 +179,24 @@ def test_stem_matches_fp32_conv7x7_bn_relu(cout, B, N, H, W):
         np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)   # bf16 output rounding
 
 
+@pytest.mark.parametrize("cout,B,N,H,W", [(64, 2, 1, 64, 64), (128, 1, 3, 64, 128), (128, 2, 2, 128, 128), (128, 1, 1, 16, 64)])
+def test_fused_stem_maxpool_equals_unfused_bit_for_bit(cout, B, N, H, W):
+    """K1+K1b fused == the (separately verified) stem kernel followed by the exact maxpool kernel."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(cout + H + W)
+    x = (torch.rand(B, 3 * N, H, W, generator=gen) - 0.45).to(_dev())
+    wp = torch.zeros(cout, 7, 8, 4)
+    wp[:, :, :7, :3] = torch.randn(cout, 7, 7, 3, generator=gen) * (2.0 / 147) ** 0.5
+    w = wp.reshape(cout, 224).to(BF16).to(_dev())
+    scale = (torch.rand(cout, generator=gen) + 0.5).to(_dev())
+    shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())      # relu(shift) != 0: catches an unmasked halo row
+    ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
+    got = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref)
+
+
 def test_maxpool_is_exact():
     from multiagentperception_amd import ops
     gen = torch.Generator().manual_seed(5)
@@ -207,6 +225,23 @@ def test_linear_matches_fp32(M, K, O, bf16_in, relu):
     if relu:
         ref = F.relu(ref)
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)   # f32 both sides, sum order only
+
+
+@pytest.mark.parametrize("M,O", [(20, 1024), (20, 32), (3, 7)])
+def test_head_tail_matches_fp32_mlp(M, O):
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(M + O)
+    h0 = F.relu(torch.randn(M, 512, generator=gen))
+    w1 = torch.randn(128, 256, generator=gen) / 16
+    b1 = torch.randn(128, generator=gen) * 0.1
+    w2 = torch.randn(O, 128, generator=gen) / 11
+    b2 = torch.randn(O, generator=gen) * 0.1
+    for col in (0, 256):                                  # the two heads read different column blocks of fc.0's output
+        out = ops.head_tail(h0.to(_dev()), col, 256, w1.t().contiguous().to(_dev()), b1.to(_dev()),
+                            w2.t().contiguous().to(_dev()), b2.to(_dev()))
+        torch.cuda.synchronize()
+        ref = F.linear(F.relu(F.linear(h0[:, col:col + 256], w1, b1)), w2, b2)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
 
 
 def _ref_graph(query, key, wq, bq, B, N, who, mode):
