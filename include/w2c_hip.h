@@ -94,6 +94,11 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
                                 void* y, int y_cstride, int y_is_f32,
                                 const void* zero_page, int variant, w2c_stream_t stream);
 
+/* Debug aid (tools/conv_timeline.py): the calling thread's NEXT w2c_conv_igemm_bf16_variant launch records
+ * 4 x uint64 wall-clock stamps per workgroup (start, first tile landed, main loop done, end; 100 MHz) into buf
+ * (device memory, >= 32 bytes x workgroups). */
+int w2c_debug_conv_timeline(void* buf);
+
 /* ---- K5: Linear (+ReLU) for the key/query heads (agent.py:150-159,167-178).
  * x : [M, K] bf16 (x_is_bf16=1, row stride x_stride elements) or f32
  * w : f32 [O, K] row-major; b : f32 [O]; y : f32 [M, O].  K multiple of 4, M <= 64 per call. */

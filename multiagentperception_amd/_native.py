@@ -26,6 +26,7 @@ SIGNATURES = {
     "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
     "w2c_conv_igemm_bf16_variant": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
                                     _vp],
+    "w2c_debug_conv_timeline": [_vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "w2c_head_tail_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp],
     "w2c_comm_graph": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

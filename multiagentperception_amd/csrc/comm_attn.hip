@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restric
 }
 
 // Head tail: out = W2 relu(W1 h0 + b1) + b2 for one head (km_generator / linear fc.2, fc.4;
-// agent.py:152-155).  One workgroup per image row; h0 / h1 live in LDS; weights are packed K-MAJOR
-// ([K][O]) so consecutive threads read consecutive outputs of one k (coalesced, L2-resident).
+// agent.py:152-155).  Workgroup = (image row m, 256-output slice); h0 / h1 live in LDS; weights are packed
+// K-MAJOR ([K][O]) so consecutive threads read consecutive outputs of one k (coalesced, L2-resident).
+// Latency-bound by construction (tiny), so every loop keeps 16 independent loads in flight; each slice
+// recomputes the 128-wide hidden layer (32 K MACs) rather than synchronising through memory.
 __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ h0, int h0_stride, int K1,
                                                         const float* __restrict__ w1t, const float* __restrict__ b1, int H1,
                                                         const float* __restrict__ w2t, const float* __restrict__ b2, int O,
@@ -147,16 +149,20 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     const int parts = 256 / H1;                            // H1 <= 256
     {
         const int j = tid % H1, part = tid / H1;
-        float a0 = 0.f, a1 = 0.f;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (part < parts) {
-            int k = part;
-            for (; k + parts < K1; k += 2 * parts) {
-                a0 = fmaf(w1t[(size_t)k * H1 + j], s_h0[k], a0);
-                a1 = fmaf(w1t[(size_t)(k + parts) * H1 + j], s_h0[k + parts], a1);
+            const int kn = (K1 - part + parts - 1) / parts;           // this partition's k count: k = part + i*parts
+            int i = 0;
+            for (; i + 15 < kn; i += 16) {
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = w1t[(size_t)(part + (i + u) * parts) * H1 + j];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a[u & 3] = fmaf(wv[u], s_h0[part + (i + u) * parts], a[u & 3]);
             }
-            for (; k < K1; k += parts) a0 = fmaf(w1t[(size_t)k * H1 + j], s_h0[k], a0);
+            for (; i < kn; ++i) a[0] = fmaf(w1t[(size_t)(part + i * parts) * H1 + j], s_h0[part + i * parts], a[0]);
         }
-        s_part[tid] = a0 + a1;
+        s_part[tid] = (a[0] + a[1]) + (a[2] + a[3]);
     }
     __syncthreads();
     if (tid < H1) {
@@ -165,18 +171,20 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         s_h1[tid] = fmaxf(v, 0.f);
     }
     __syncthreads();
-    // layer 2: thread = output o (strided), K = H1
-    for (int o = tid; o < O; o += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // layer 2: thread = one output of this workgroup's slice, K = H1
+    const int o = blockIdx.y * 256 + tid;
+    if (o < O) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         int k = 0;
-        for (; k + 3 < H1; k += 4) {
-            a0 = fmaf(w2t[(size_t)k * O + o], s_h1[k], a0);
-            a1 = fmaf(w2t[(size_t)(k + 1) * O + o], s_h1[k + 1], a1);
-            a2 = fmaf(w2t[(size_t)(k + 2) * O + o], s_h1[k + 2], a2);
-            a3 = fmaf(w2t[(size_t)(k + 3) * O + o], s_h1[k + 3], a3);
+        for (; k + 15 < H1; k += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w2t[(size_t)(k + u) * O + o];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u & 3] = fmaf(wv[u], s_h1[k + u], a[u & 3]);
         }
-        for (; k < H1; ++k) a0 = fmaf(w2t[(size_t)k * O + o], s_h1[k], a0);
-        out[(size_t)m * O + o] = (a0 + a1) + (a2 + a3) + b2[o];
+        for (; k < H1; ++k) a[0] = fmaf(w2t[(size_t)k * O + o], s_h1[k], a[0]);
+        out[(size_t)m * O + o] = (a[0] + a[1]) + (a[2] + a[3]) + b2[o];
     }
 }
 
@@ -370,7 +378,7 @@ extern "C" int w2c_head_tail_f32(const float* h0, int h0_stride, int M, int K1, 
     if (!h0 || !w1t || !b1 || !w2t || !b2 || !out || M <= 0 || K1 <= 0 || H1 <= 0 || H1 > 256 || O <= 0) return W2C_E_ARG;
     if (h0_stride < K1) return W2C_E_ARG;
     const size_t lds = (size_t)(K1 + H1 + 256) * 4;
-    hipLaunchKernelGGL(head_tail_kernel, dim3(M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(head_tail_kernel, dim3(M, (O + 255) / 256), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        h0, h0_stride, K1, w1t, b1, H1, w2t, b2, O, out);
     return w2c_launch_status();
 }

@@ -28,6 +28,7 @@
 // XORs make each group's 16 (row-in-bank-row, position) pairs distinct => conflict-free
 // (MI355X_MICROARCH.md LDS table).
 #include "w2c_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -47,7 +48,13 @@ struct ConvArgs {
     int cin_tiles;   // Cin / BK
     int ktiles;      // ks*ks*cin_tiles
     int ntm, ntn;    // tiles along rows / cout
+    unsigned long long* dbg;   // optional timeline buffer (tools/conv_timeline.py): 4 x u64 per workgroup, else null
 };
+
+__device__ __forceinline__ void dbg_stamp(const ConvArgs& p, int slot) {
+    if (p.dbg && threadIdx.x == 0)
+        p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + slot] = wall_clock64();
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.y;
 
+    dbg_stamp(p, 0);
     // ---- tile id (XCD-aware): n fastest so the column tiles of one row panel share an L2 ----
     const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
     const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
@@ -161,6 +169,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int lswz = swz(l31);             // tile / wave offsets are multiples of 32: swz(row) == swz(l31)
+    // epilogue constants fetched now: their latency hides under the main loop
+    float e_sc[NI], e_sh[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        e_sc[j] = p.scale[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
+        e_sh[j] = p.shift[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
+    }
 
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE_BYTES;
@@ -196,20 +211,44 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         if (t + STAGES - 2 < KT) wait_vmcnt<(STAGES - 2) * LOADS>();     // tile t (my part) has landed
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                                    // everyone's part landed; tile t-1's buffer is free
+        if (t == 0) dbg_stamp(p, 1);
         if (t + STAGES - 1 < KT) stage(wr);
         compute(rd);
         rd = (rd + 1 == STAGES) ? 0 : rd + 1;
         wr = (wr + 1 == STAGES) ? 0 : wr + 1;
     }
     __builtin_amdgcn_s_barrier();    // every wave done reading the ring; reuse LDS for the epilogue
+    dbg_stamp(p, 2);
 
+    // ---- epilogue 0: residual addresses + loads FIRST (branch-free, clamped), so their HBM latency runs
+    // under the LDS staging below and is paid once, not per pass ----
+    constexpr int CG = BN / 8;                     // 8-channel groups per row
+    constexpr int PASSES = BM * CG / NT;
+    static_assert(PASSES * NT == BM * CG, "epilogue split");
+    size_t e_off[PASSES];
+    bool e_ok[PASSES];
+    uint4 e_res[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = ps * NT + tid;
+        const int r = idx / CG, cg = idx - r * CG;
+        const int gr = m0 + r;
+        e_ok[ps] = gr < p.rows;
+        e_off[ps] = (size_t)(e_ok[ps] ? gr : 0) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
+    }
+    if (p.res) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) e_res[ps] = *reinterpret_cast<const uint4*>(p.res + e_off[ps]);
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) e_res[ps] = make_uint4(0, 0, 0, 0);
+    }
     // ---- epilogue 1: scale/shift in registers, tile -> LDS as f32 [BM][CLD] ----
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int nl = wn * WTN + j * 32 + l31;
-        const float sc = p.scale[g * p.Cout + n0 + nl];
-        const float sh = p.shift[g * p.Cout + n0 + nl];
+        const float sc = e_sc[j], sh = e_sh[j];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -222,43 +261,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     __syncthreads();
 
     // ---- epilogue 2: coalesced (+residual) (+ReLU) store, 8 channels per thread per pass ----
-    constexpr int CG = BN / 8;                     // 8-channel groups per row
-    constexpr int PASSES = BM * CG / NT;
-    static_assert(PASSES * NT == BM * CG, "epilogue split");
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * NT + tid;
         const int r = idx / CG, cg = idx - r * CG;
-        const int gr = m0 + r;
-        if (gr >= p.rows) continue;
         const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8);
         const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const size_t off = (size_t)gr * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
-        if (p.res) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(p.res + off);
-            const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+        const uint32_t rw[4] = {e_res[ps].x, e_res[ps].y, e_res[ps].z, e_res[ps].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFFu));
-                v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
-            }
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFFu));        // +0 when there is no residual
+            v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
         }
         if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.y_f32) {
-            float* yo = reinterpret_cast<float*>(p.y) + off;
-            *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
-        } else {
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + off) = o;
+        if (e_ok[ps]) {
+            if (p.y_f32) {
+                float* yo = reinterpret_cast<float*>(p.y) + e_off[ps];
+                *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+            } else {
+                uint4 o;
+                o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + e_off[ps]) = o;
+            }
         }
     }
+    dbg_stamp(p, 3);
 }
 
 // =====================================================================================================
@@ -274,20 +307,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 // one barrier per tap, counted vmcnt, patch double-buffered across channel chunks.
 // LDS patch image: one 128-B row per patch pixel, 16-B chunk c of pixel q at c ^ ((q>>1)&7) -- the
 // ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
-template <int TH, int TW, int BN, int STAGES>
-__global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
+template <int TH, int TW, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
     constexpr int BM = TH * TW;
-    constexpr int NW = 8, WM = 4, WN = 2, NT = 512;
+    constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
     constexpr int PW = TW + 2, PH = TH + 2, NP = PH * PW;
-    constexpr int NP_PAD = (NP + 63) / 64 * 64;
-    constexpr int P_INSTR = NP_PAD / 64;               // patch DMA instructions per wave per chunk (8 pixels each)
-    constexpr int PATCH_BYTES = NP_PAD * 128;
+    constexpr int P_INSTR = (NP + 8 * NW - 1) / (8 * NW);   // patch DMA instructions per wave per chunk (8 pixels each,
+                                                            // lanes past the last patch pixel are predicated off)
+    constexpr int PATCH_BYTES = NP * 128;
     constexpr int B_BYTES = BN * 128;
     constexpr int B_INSTR = BN / 8 / NW;               // weight DMA instructions per wave per tap
     constexpr int CLD = BN + 4;
-    static_assert(BM == 256 && MI == 2 && (NI == 1 || NI == 2) && B_INSTR >= 1, "shape");
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN && B_INSTR >= 1, "shape");
     static_assert(STAGES >= 2 && (STAGES - 2) * B_INSTR + P_INSTR < 64, "vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -300,6 +333,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
     const int g = blockIdx.y;
     const int lrow = lane >> 3, lpos = lane & 7;
 
+    dbg_stamp(p, 0);
     // ---- tile decode: n fastest, then x, y, image ----
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
     const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
@@ -315,26 +349,32 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
     const int nchunks = p.Cin >> 6;
     const int KT = nchunks * 9;
 
-    // ---- patch gather addresses (fixed per tile; + 64*chunk per channel chunk) ----
-    long pa_off[P_INSTR];      // element offset, or -1 => zero page
-    int pa_zoff[P_INSTR];
-#pragma unroll
-    for (int j = 0; j < P_INSTR; ++j) {
-        const int q = (wave + NW * j) * 8 + lrow;              // patch pixel index
-        const int chunk = lpos ^ ((q >> 1) & 7);
-        pa_zoff[j] = chunk * 8;
-        const int py = q / PW, px = q - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = (q < NP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        pa_off[j] = ok ? (((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8 : -1;
-    }
+    // ---- patch gather (addresses recomputed per chunk: once per 9 taps, keeps ~20 VGPRs free) ----
+    // Rounds whose first pixel is past the patch are skipped by the whole wave (wave-uniform test), so the
+    // number of VMEM ops a wave has in flight is EXACTLY known: the last round exists only for some waves.
+    const bool p_last = (wave + NW * (P_INSTR - 1)) * 8 < NP;       // does this wave issue round P_INSTR-1 ?
     auto issue_patch = [&](int cc, int buf) {
         char* dst = patch0 + buf * PATCH_BYTES;
 #pragma unroll
         for (int j = 0; j < P_INSTR; ++j) {
-            const uint16_t* src = pa_off[j] >= 0 ? xg + (pa_off[j] + cc * 64) : p.zeros + pa_zoff[j];
-            __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(dst + (wave + NW * j) * 1024), 16, 0, 0);
+            if ((wave + NW * j) * 8 < NP) {                          // wave-uniform
+                const int q = (wave + NW * j) * 8 + lrow;            // patch pixel index
+                const int chunk = lpos ^ ((q >> 1) & 7);
+                const int py = q / PW, px = q - py * PW;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const uint16_t* src = ok ? xg + ((((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8 + cc * 64)
+                                         : p.zeros + chunk * 8;
+                if (q < NP)            // lanes past the last patch pixel do not write LDS (buffers are not padded)
+                    __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(dst + (wave + NW * j) * 1024), 16, 0, 0);
+            }
         }
+    };
+    // wait until at most (K weight-tile DMAs + one patch chunk) of this wave's VMEM ops are outstanding
+    auto wait_tiles_and_patch = [&](auto ktag) {
+        constexpr int K = decltype(ktag)::value;
+        if (p_last) wait_vmcnt<K * B_INSTR + P_INSTR>();
+        else wait_vmcnt<K * B_INSTR + P_INSTR - 1>();
     };
     // ---- weight tile addresses ----
     const uint16_t* b_src[B_INSTR];
@@ -370,9 +410,15 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
         pp0[i] = (tp / TW) * PW + (tp % TW);
     }
     const int bswz = (l31 >> 1) & 7;
+    float e_sc[NI], e_sh[NI];                                   // epilogue constants: latency hidden by the main loop
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        e_sc[j] = p.scale[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
+        e_sh[j] = p.shift[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
+    }
 
-    auto compute = [&](const char* patch, const char* Bs, int dk) {
-        bf16x8_t a[4][MI], b[4][NI];
+    bf16x8_t fa[4][MI], fb[4][NI];                              // fragment registers of ONE K-step (tap)
+    auto load_frags = [&](const char* patch, const char* Bs, int dk) {
         const char* arow[MI];
         int aswz[MI];
 #pragma unroll
@@ -385,22 +431,27 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                a[kk][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + (((kk * 2 + lhi) ^ aswz[i]) << 4));
+                fa[kk][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + (((kk * 2 + lhi) ^ aswz[i]) << 4));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                b[kk][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WTN + j * 32 + l31) * 128 +
-                                                              (((kk * 2 + lhi) ^ bswz) << 4));
+                fb[kk][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WTN + j * 32 + l31) * 128 +
+                                                               (((kk * 2 + lhi) ^ bswz) << 4));
         }
+    };
+    auto mfma_all = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
     };
+    using KS2 = std::integral_constant<int, STAGES - 2>;
 
-    // ---- pipeline: patch(cc+1) prefetched at tap 0 of chunk cc; weight tiles STAGES-1 ahead ----
+    // ---- lock-step pipeline: patch(cc+1) prefetched at tap 0 of chunk cc; weight tiles STAGES-1 ahead ----
+    // (An 8-wave "ping-pong" variant -- wave groups half an epoch apart -- and a runtime tap loop were both
+    //  measured slower than this fully unrolled form on MI355X: profiles/r01_b_conv_variant_sweep.txt.)
     issue_patch(0, 0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
@@ -414,28 +465,49 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
             // Younger loads allowed in flight: STAGES-2 weight tiles, plus patch(cc+1) while it is
             // younger than tile t (it was issued right after tile t0+STAGES-1 at tap 0).
             if (t + STAGES - 2 < KT) {
-                if (more && tap >= 1 && tap <= STAGES - 1) wait_vmcnt<(STAGES - 2) * B_INSTR + P_INSTR>();
+                if (more && tap >= 1 && tap <= STAGES - 1) wait_tiles_and_patch(KS2{});
                 else wait_vmcnt<(STAGES - 2) * B_INSTR>();
             } else {
                 wait_vmcnt<0>();
             }
             __builtin_amdgcn_s_barrier();
+            if (t == 0) dbg_stamp(p, 1);
             if (t + STAGES - 1 < KT) issue_b(wr);
             if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
-            compute(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3));
+            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3));
+            mfma_all();
             rd = (rd + 1 == STAGES) ? 0 : rd + 1;
             wr = (wr + 1 == STAGES) ? 0 : wr + 1;
         }
     }
     __builtin_amdgcn_s_barrier();
+    dbg_stamp(p, 2);
 
     // ---- epilogue (same contract as the generic kernel; tile row r -> pixel (y0 + r/TW, x0 + r%TW)) ----
+    constexpr int CG = BN / 8;
+    constexpr int PASSES = BM * CG / NT;
+    static_assert(PASSES * NT == BM * CG, "epilogue split");
+    size_t e_off[PASSES];
+    uint4 e_res[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = ps * NT + tid;
+        const int r = idx / CG, cg = idx - r * CG;
+        const int oy = y0 + r / TW, ox = x0 + r % TW;
+        e_off[ps] = (((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
+    }
+    if (p.res) {                                   // all residual loads in flight together, under the LDS staging
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) e_res[ps] = *reinterpret_cast<const uint4*>(p.res + e_off[ps]);
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) e_res[ps] = make_uint4(0, 0, 0, 0);
+    }
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int nl = wn * WTN + j * 32 + l31;
-        const float sc = p.scale[g * p.Cout + n0 + nl];
-        const float sh = p.shift[g * p.Cout + n0 + nl];
+        const float sc = e_sc[j], sh = e_sh[j];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -445,51 +517,44 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(ConvArgs p) {
             }
     }
     __syncthreads();
-    constexpr int CG = BN / 8;
-    constexpr int PASSES = BM * CG / NT;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * NT + tid;
         const int r = idx / CG, cg = idx - r * CG;
-        const int oy = y0 + r / TW, ox = x0 + r % TW;
         const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8);
         const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const size_t off = (((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
-        if (p.res) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(p.res + off);
-            const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+        const uint32_t rw[4] = {e_res[ps].x, e_res[ps].y, e_res[ps].z, e_res[ps].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFFu));
-                v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
-            }
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFFu));
+            v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
         }
         if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.y_f32) {
-            float* yo = reinterpret_cast<float*>(p.y) + off;
+            float* yo = reinterpret_cast<float*>(p.y) + e_off[ps];
             *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
         } else {
             uint4 o;
             o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
             o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + off) = o;
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + e_off[ps]) = o;
         }
     }
+    dbg_stamp(p, 3);
 }
 
-template <int TH, int TW, int BN, int STAGES>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
         return W2C_E_ARG;
     a.ntm = a.M * (a.H / TH) * (a.W / TW);
     a.ntn = a.Cout / BN;
-    constexpr int NP_PAD = ((TH + 2) * (TW + 2) + 63) / 64 * 64;
-    constexpr int ring = 2 * NP_PAD * 128 + STAGES * BN * 128;
+    constexpr int ring = 2 * (TH + 2) * (TW + 2) * 128 + STAGES * BN * 128;
     constexpr int epi = TH * TW * (BN + 4) * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS");
@@ -497,12 +562,12 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, STAGES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, STAGES>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -556,33 +621,36 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 14: return launch_conv<128, 64, 2, 2, 64, 4>(a, groups, s);
         case 15: return launch_conv<256, 64, 4, 1, 64, 3>(a, groups, s);   // 4 waves, 64x64 wave tile
         // patch-staged 3x3 stride-1 kernels (TH x TW pixel tile, BN, weight-ring stages)
-        case 20: return launch_patch<8, 32, 128, 3>(a, groups, s);
-        case 21: return launch_patch<8, 32, 128, 2>(a, groups, s);
-        case 22: return launch_patch<8, 32, 64, 3>(a, groups, s);
-        case 23: return launch_patch<16, 16, 128, 3>(a, groups, s);
-        case 24: return launch_patch<16, 16, 64, 3>(a, groups, s);
-        case 25: return launch_patch<8, 32, 64, 4>(a, groups, s);
-        case 26: return launch_patch<16, 16, 128, 2>(a, groups, s);
+        case 20: return launch_patch<8, 32, 128, 4, 2, 3>(a, groups, s);
+        case 21: return launch_patch<8, 32, 128, 4, 2, 2>(a, groups, s);
+        case 22: return launch_patch<8, 32, 64, 4, 2, 3>(a, groups, s);
+        case 23: return launch_patch<16, 16, 128, 4, 2, 3>(a, groups, s);
+        case 24: return launch_patch<16, 16, 64, 4, 2, 3>(a, groups, s);
+        case 25: return launch_patch<8, 32, 64, 4, 2, 4>(a, groups, s);
+        case 26: return launch_patch<16, 16, 128, 4, 2, 2>(a, groups, s);
+        // 4-wave, 128-pixel tiles: <= 80 KB of LDS so TWO workgroups share a CU (one's prologue /
+        // epilogue under the other's MFMAs)
+        case 30: return launch_patch<8, 16, 128, 2, 2, 2>(a, groups, s);
+        case 31: return launch_patch<8, 16, 64, 2, 2, 3>(a, groups, s);
+        case 32: return launch_patch<4, 32, 128, 2, 2, 2>(a, groups, s);
+        case 33: return launch_patch<4, 32, 64, 2, 2, 3>(a, groups, s);
+        case 34: return launch_patch<8, 16, 64, 2, 2, 2>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
 
 // Per-layer kernel choice, from the per-layer sweeps of tools/bench_conv.py on MI355X
-// (profiles/r01_b_conv_variant_sweep.txt).  Stride-1 3x3 convs with >= 128 input channels go to the
-// patch-staged kernel when it can put >= 128 workgroups of 256 pixels on the chip; everything else
-// (stride 2, 1x1, 64-channel layer1, tiny tail layers) to the generic implicit GEMM, whose tile is
-// chosen to keep >= ~2 workgroups per CU.
+// (profiles/r01_b_conv_variant_sweep.txt).  Stride-1 3x3 convs go to the patch-staged kernel with 128-pixel
+// (8x16) tiles and 4 waves -- <= 80 KB of LDS, so two workgroups share a CU -- 128 output channels wide when
+// that still yields >= 256 workgroups, else 64 wide; everything else (stride 2, 1x1, maps narrower than 16
+// pixels) to the generic implicit GEMM, whose tile is chosen to keep >= ~2 workgroups per CU.
 int pick_variant(const ConvArgs& a, int groups) {
     const long rows = a.rows;
     const int Cout = a.Cout;
-    if (a.ks == 3 && a.stride == 1 && a.Cin >= 128 && a.H % 16 == 0 && a.W % 16 == 0) {
-        const long tiles = (long)a.M * (a.H / 16) * (a.W / 16) * groups;
-        const long c128 = (Cout % 128 == 0) ? tiles * (Cout / 128) : 0;
-        const long c64 = (Cout % 64 == 0) ? tiles * (Cout / 64) : 0;
-        if (c128 >= 512) return 26;
-        if (c64 >= 512) return 24;
-        if (c128 >= 128) return 26;
-        if (c64 >= 128) return 24;
+    if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
+        const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
+        if (Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
+        if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return a.Cin == 64 ? 34 : 31;
     }
     if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return 0;
     if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
@@ -608,6 +676,7 @@ int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int 
     a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
     a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;
     a.rows = M * a.Ho * a.Wo;
+    a.dbg = nullptr;
     return W2C_OK;
 }
 
@@ -628,6 +697,14 @@ extern "C" int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int C
     return launch_variant(pick_variant(a, groups), a, groups, s);
 }
 
+// Debug: next w2c_conv_igemm_bf16_variant call of THIS thread writes a workgroup timeline (4 x u64
+// wall_clock64 stamps per workgroup: start, first tile landed, main loop done, end) to `buf`.
+static thread_local unsigned long long* g_dbg_next = nullptr;
+extern "C" int w2c_debug_conv_timeline(void* buf) {
+    g_dbg_next = reinterpret_cast<unsigned long long*>(buf);
+    return W2C_OK;
+}
+
 extern "C" int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
                                            const uint16_t* w, int Cout, int ksize, int stride, int groups,
                                            const float* scale, const float* shift,
@@ -639,5 +716,7 @@ extern "C" int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int 
     int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
                        y, y_cstride, y_is_f32, zero_page);
     if (rc != W2C_OK) return rc;
+    a.dbg = g_dbg_next;
+    g_dbg_next = nullptr;
     return launch_variant(variant, a, groups, reinterpret_cast<hipStream_t>(stream));
 }

@@ -124,10 +124,12 @@ VARIANT_CASES = [
     (20, 2, 8, 32, 128, 128, 3, 1, 2, True), (21, 1, 16, 64, 64, 128, 3, 1, 1, False), (22, 2, 8, 32, 256, 64, 3, 1, 1, True),
     (23, 3, 16, 16, 128, 256, 3, 1, 2, True), (24, 1, 32, 16, 192, 64, 3, 1, 1, False), (25, 1, 8, 64, 64, 64, 3, 1, 2, True),
     (26, 2, 16, 32, 512, 128, 3, 1, 1, True),
+    (30, 2, 8, 32, 128, 128, 3, 1, 2, True), (31, 1, 16, 16, 192, 64, 3, 1, 1, False), (32, 1, 8, 64, 64, 128, 3, 1, 1, True),
+    (33, 3, 4, 32, 128, 64, 3, 1, 2, True), (34, 1, 24, 16, 64, 64, 3, 1, 1, True),
 ]
 
 
-@pytest.mark.parametrize("case", VARIANT_CASES, ids=["v%d" % c[0] for c in VARIANT_CASES])
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=["v%d-%d" % (c[0], i) for i, c in enumerate(VARIANT_CASES)])
 def test_conv_variants_match_fp32_conv(case):
     """Every tile/pipeline variant (generic ring depths, 8-wave tiles, patch-staged) against fp32."""
     from multiagentperception_amd import ops

@@ -33,8 +33,10 @@ VALID = {  # variant -> (BM, BN, BK)
     12: (128, 128, 32), 13: (64, 64, 64), 14: (128, 64, 64), 15: (256, 64, 64),
     20: (256, 128, 64), 21: (256, 128, 64), 22: (256, 64, 64), 23: (256, 128, 64), 24: (256, 64, 64), 25: (256, 64, 64),
     26: (256, 128, 64),
+    30: (128, 128, 64), 31: (128, 64, 64), 32: (128, 128, 64), 33: (128, 64, 64), 34: (128, 64, 64),
 }
-PATCH_GEOM = {20: (8, 32), 21: (8, 32), 22: (8, 32), 23: (16, 16), 24: (16, 16), 25: (8, 32), 26: (16, 16)}
+PATCH_GEOM = {20: (8, 32), 21: (8, 32), 22: (8, 32), 23: (16, 16), 24: (16, 16), 25: (8, 32), 26: (16, 16),
+              30: (8, 16), 31: (8, 16), 32: (4, 32), 33: (4, 32), 34: (8, 16)}
 
 
 def main():
