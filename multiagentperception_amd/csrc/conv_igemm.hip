@@ -450,8 +450,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     using KS2 = std::integral_constant<int, STAGES - 2>;
 
     // ---- lock-step pipeline: patch(cc+1) prefetched at tap 0 of chunk cc; weight tiles STAGES-1 ahead ----
-    // (An 8-wave "ping-pong" variant -- wave groups half an epoch apart -- and a runtime tap loop were both
-    //  measured slower than this fully unrolled form on MI355X: profiles/r01_b_conv_variant_sweep.txt.)
+    // (Measured and rejected on MI355X, see profiles/r01_b_conv_variant_sweep.txt: an 8-wave "ping-pong"
+    //  variant with wave groups half an epoch apart, a runtime tap loop, and a persistent cross-tile-
+    //  prefetching version with a 32-row multi-pass epilogue -- all slower than this unrolled lock-step form.)
     issue_patch(0, 0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
