@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     // so the HBM round trip hides behind the matrix work instead of stalling each tile six times.
     constexpr int FILL = (PATCH_ROWS * PATCH_COLS + 255) / 256;         // 6
     float pv[FILL][3];
+    unsigned pmask = 0;                                  // bit f: patch pixel f of this thread is inside the image
     auto load_patch = [&](int ox0) {
         const int iy_base = 2 * oy0 - 3, ix_base = 2 * ox0 - 3;
 #pragma unroll
@@ -73,18 +74,19 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             const int iy = iy_base + r, ix = ix_base + c;
             const bool ok = (pidx < PATCH_ROWS * PATCH_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
             const size_t o = ok ? (size_t)iy * W + ix : 0;              // clamp: always a valid address
-            const float a0 = xin[o], a1 = xin[o + (size_t)H * W], a2 = xin[o + 2 * (size_t)H * W];
-            pv[f][0] = ok ? a0 : 0.f;
-            pv[f][1] = ok ? a1 : 0.f;
-            pv[f][2] = ok ? a2 : 0.f;
+            // keep the RAW loaded values: masking here would make the compiler wait for the loads right away
+            // (the select cannot sink across the barriers below); the mask is applied in store_patch().
+            pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];
+            pmask = ok ? (pmask | (1u << f)) : (pmask & ~(1u << f));
         }
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int f = 0; f < FILL; ++f) {
             const int pidx = tid + f * 256;
+            const bool ok = (pmask >> f) & 1u;
             if (pidx < PATCH_ROWS * PATCH_COLS)
-                patch[pidx] = make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f));
+                patch[pidx] = ok ? make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f)) : make_uint2(0u, 0u);
         }
     };
 
@@ -196,8 +198,15 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict_
                 wf[ky][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ky * 32 + (ks * 2 + lhi) * 8);
     }
 
+    f32x4_t e_sc[4], e_sh[4];               // BN scale / shift of this wave's 32 channels (fixed for the kernel)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        e_sc[q] = *reinterpret_cast<const f32x4_t*>(scale + ct * 32 + 8 * q + 4 * lhi);
+        e_sh[q] = *reinterpret_cast<const f32x4_t*>(shift + ct * 32 + 8 * q + 4 * lhi);
+    }
     constexpr int FILL = (FP_ROWS * FP_COLS + 511) / 512;               // 4
     float pv[FILL][3];
+    unsigned pmask = 0;
     auto load_patch = [&](int ox0) {
         const int iy_base = 2 * oy0 - 5, ix_base = 2 * ox0 - 3;         // conv row oy0-1 needs input row 2*(oy0-1)-3
 #pragma unroll
@@ -207,18 +216,17 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict_
             const int iy = iy_base + r, ix = ix_base + c;
             const bool ok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
             const size_t o = ok ? (size_t)iy * W + ix : 0;
-            const float a0 = xin[o], a1 = xin[o + (size_t)H * W], a2 = xin[o + 2 * (size_t)H * W];
-            pv[f][0] = ok ? a0 : 0.f;
-            pv[f][1] = ok ? a1 : 0.f;
-            pv[f][2] = ok ? a2 : 0.f;
+            pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];   // raw, masked at store
+            pmask = ok ? (pmask | (1u << f)) : (pmask & ~(1u << f));
         }
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int f = 0; f < FILL; ++f) {
             const int pidx = tid + f * 512;
+            const bool ok = (pmask >> f) & 1u;
             if (pidx < FP_ROWS * FP_COLS)
-                patch[pidx] = make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f));
+                patch[pidx] = ok ? make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f)) : make_uint2(0u, 0u);
         }
     };
     auto stg_addr = [&](int row, int col, int chunk) -> char* {
@@ -258,9 +266,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict_
         // BN + ReLU -> bf16 -> staging[mt][1 + l31][channels]; conv row oy0-1+mt < 0 is outside the image
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ch = ct * 32 + 8 * q + 4 * lhi;
-            const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + ch);
-            const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(shift + ch);
+            const f32x4_t sc = e_sc[q], sh = e_sh[q];
 #pragma unroll
             for (int m = 0; m < MT_MAX; ++m) {
                 const int mt = mt_lo + m;
