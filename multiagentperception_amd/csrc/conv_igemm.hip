@@ -63,6 +63,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int BM, int BN, int WM, int WN, int BK, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;        // wave tile
     constexpr int MI = WTM / 32, NI = WTN / 32;        // 32x32 MFMA tiles per wave
@@ -97,19 +98,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const int Ktot = p.ktiles * BK;
     const uint16_t* wg = p.w + (size_t)g * p.Cout * Ktot;              // group's weights
 
-    // ---- per-thread gather state for its A rows (fixed for the whole K loop) ----
+    // ---- DMA addressing: buffer loads to LDS (SGPR descriptor + per-lane 32-bit byte offset + scalar
+    // channel-chunk offset).  A row's offset for tap (ky,kx) is base + tap_off with tap_off wave-uniform;
+    // taps that fall outside the image (and rows past the end) get an offset past the descriptor's extent, so
+    // the hardware bounds check writes zeros into LDS -- no zero page, no 64-bit per-lane address math. ----
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(wg), 0, (int)((size_t)p.Cout * Ktot * 2), 0x00020000);
     const int lrow = lane / LPR;           // row within a DMA group
     const int lpos = lane % LPR;           // 16-B position within the LDS row
     auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     int a_iy0[A_INSTR], a_ix0[A_INSTR];
-    long a_off[A_INSTR];                   // element offset of (image, iy0, ix0) + chunk; row validity folded into iy0
-    int a_zoff[A_INSTR];
+    int a_base[A_INSTR];                   // byte offset of (image, iy0, ix0, chunk); may be negative before the tap is added
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
         const int r = (wave + NW * j) * RPI + lrow;
         const int gr = m0 + r;
         const int chunk = lpos ^ swz(r);
-        a_zoff[j] = chunk * 8;
         if (gr < p.rows) {
             const int hw = p.Ho * p.Wo;
             const int m = gr / hw;
@@ -117,17 +123,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_iy0[j] = oy * p.stride - p.pad;
             a_ix0[j] = ox * p.stride - p.pad;
-            a_off[j] = ((long)m * p.H * p.W + (long)a_iy0[j] * p.W + a_ix0[j]) * p.xcs + chunk * 8;
+            a_base[j] = (int)((((long)m * p.H * p.W + (long)a_iy0[j] * p.W + a_ix0[j]) * p.xcs + chunk * 8) * 2);
         } else {
-            a_iy0[j] = -100000; a_ix0[j] = 0; a_off[j] = 0;       // every tap out of range -> zero page
+            a_iy0[j] = -100000; a_ix0[j] = 0; a_base[j] = 0;      // every tap out of range -> zeros
         }
     }
-    const uint16_t* b_src[B_INSTR];
+    unsigned b_off[B_INSTR];
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
         const int n = (wave + NW * j) * RPI + lrow;
-        const int chunk = lpos ^ swz(n);
-        b_src[j] = wg + (size_t)(n0 + n) * Ktot + chunk * 8;
+        b_off[j] = (unsigned)(((size_t)(n0 + n) * Ktot + (lpos ^ swz(n)) * 8) * 2);
     }
 
     // K-step cursor (wave-uniform): tap (ky,kx) and channel chunk
@@ -136,21 +141,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     auto stage = [&](int buf) {
         char* As = smem + buf * STAGE_BYTES;
         char* Bs = As + A_BYTES;
-        const long tap_off = ((long)st_ky * p.W + st_kx) * p.xcs + st_ct * BK;     // wave-uniform
+        const int tap_off = (st_ky * p.W + st_kx) * p.xcs * 2;       // wave-uniform, bytes
+        const int c_off = st_ct * BK * 2;                            // channel chunk, bytes (scalar offset)
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
             const int iy = a_iy0[j] + st_ky, ix = a_ix0[j] + st_kx;
             const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            const uint16_t* real = xg + (a_off[j] + tap_off);
-            const uint16_t* zero = p.zeros + a_zoff[j];
-            const uint16_t* src = ok ? real : zero;
-            __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(As + (wave + NW * j) * 1024), 16, 0, 0);
+            const unsigned vo = ok ? (unsigned)(a_base[j] + tap_off) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(As + (wave + NW * j) * 1024), 16, vo, c_off, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < B_INSTR; ++j) {
-            __builtin_amdgcn_global_load_lds(W2C_GPTR(b_src[j] + (size_t)st_kt * BK),
-                                             W2C_LPTR(Bs + (wave + NW * j) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < B_INSTR; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(Bs + (wave + NW * j) * 1024), 16, b_off[j],
+                                                     st_kt * BK * 2, 0, 0);
         ++st_kt;
         if (++st_ct == p.cin_tiles) {
             st_ct = 0;
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         }
     }
     dbg_stamp(p, 3);
+#endif
 }
 
 // =====================================================================================================
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 // ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
 template <int TH, int TW, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int BM = TH * TW;
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -349,24 +354,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     const int nchunks = p.Cin >> 6;
     const int KT = nchunks * 9;
 
-    // ---- patch gather (addresses recomputed per chunk: once per 9 taps, keeps ~20 VGPRs free) ----
+    // ---- DMA addressing: buffer loads to LDS.  Each lane's byte offset inside the tensor is fixed for the
+    // whole tile (a VGPR), the K-step / channel-chunk advance is a scalar offset, the base lives in an SGPR
+    // descriptor: no per-step VALU address math (measured: ~500 of ~1560 cycles per K-step went into issuing
+    // flat 64-bit-address LDS-DMA, tools/conv_phases.py).  Halo pixels outside the image carry an offset
+    // past the descriptor's extent, so the hardware bounds check writes zeros -- no zero page, no select.
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(wg), 0, (int)((size_t)p.Cout * Ktot * 2), 0x00020000);
     // Rounds whose first pixel is past the patch are skipped by the whole wave (wave-uniform test), so the
     // number of VMEM ops a wave has in flight is EXACTLY known: the last round exists only for some waves.
     const bool p_last = (wave + NW * (P_INSTR - 1)) * 8 < NP;       // does this wave issue round P_INSTR-1 ?
+    unsigned pa_off[P_INSTR];                                       // byte offset of this lane's 16 B, or out of range
+#pragma unroll
+    for (int j = 0; j < P_INSTR; ++j) {
+        const int q = (wave + NW * j) * 8 + lrow;                    // patch pixel index
+        const int chunk = lpos ^ ((q >> 1) & 7);
+        const int py = q / PW, px = q - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        pa_off[j] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8) * 2) : 0x80000000u;
+    }
     auto issue_patch = [&](int cc, int buf) {
         char* dst = patch0 + buf * PATCH_BYTES;
 #pragma unroll
         for (int j = 0; j < P_INSTR; ++j) {
             if ((wave + NW * j) * 8 < NP) {                          // wave-uniform
-                const int q = (wave + NW * j) * 8 + lrow;            // patch pixel index
-                const int chunk = lpos ^ ((q >> 1) & 7);
-                const int py = q / PW, px = q - py * PW;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                const uint16_t* src = ok ? xg + ((((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8 + cc * 64)
-                                         : p.zeros + chunk * 8;
-                if (q < NP)            // lanes past the last patch pixel do not write LDS (buffers are not padded)
-                    __builtin_amdgcn_global_load_lds(W2C_GPTR(src), W2C_LPTR(dst + (wave + NW * j) * 1024), 16, 0, 0);
+                if ((wave + NW * j) * 8 + lrow < NP)   // lanes past the last patch pixel do not write LDS (no padding)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(dst + (wave + NW * j) * 1024), 16,
+                                                             pa_off[j], cc * 128, 0, 0);
             }
         }
     };
@@ -377,19 +394,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         else wait_vmcnt<K * B_INSTR + P_INSTR - 1>();
     };
     // ---- weight tile addresses ----
-    const uint16_t* b_src[B_INSTR];
+    unsigned b_off[B_INSTR];
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
         const int n = (wave + NW * j) * 8 + lrow;
-        b_src[j] = wg + (size_t)(n0 + n) * Ktot + (lpos ^ ((n >> 1) & 7)) * 8;
+        b_off[j] = (unsigned)(((size_t)(n0 + n) * Ktot + (lpos ^ ((n >> 1) & 7)) * 8) * 2);
     }
     int st_tap = 0, st_cc = 0;                                  // cursor of the next weight tile to issue
     auto issue_b = [&](int buf) {
         char* dst = bring + buf * B_BYTES;
-        const int koff = st_tap * p.Cin + st_cc * 64;
+        const int koff = (st_tap * p.Cin + st_cc * 64) * 2;     // scalar byte offset of the K-step
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j)
-            __builtin_amdgcn_global_load_lds(W2C_GPTR(b_src[j] + koff), W2C_LPTR(dst + (wave + NW * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(dst + (wave + NW * j) * 1024), 16, b_off[j], koff, 0, 0);
         if (++st_tap == 9) { st_tap = 0; ++st_cc; }
     };
 
@@ -453,6 +470,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     // (Measured and rejected on MI355X, see profiles/r01_b_conv_variant_sweep.txt: an 8-wave "ping-pong"
     //  variant with wave groups half an epoch apart, a runtime tap loop, and a persistent cross-tile-
     //  prefetching version with a 32-row multi-pass epilogue -- all slower than this unrolled lock-step form.)
+#ifdef W2C_PHASE_TIMING
+    long long ph[5] = {0, 0, 0, 0, 0};
+#endif
     issue_patch(0, 0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
@@ -465,24 +485,50 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
             // wait until weight tile t (and everything older, incl. this chunk's patch) has landed.
             // Younger loads allowed in flight: STAGES-2 weight tiles, plus patch(cc+1) while it is
             // younger than tile t (it was issued right after tile t0+STAGES-1 at tap 0).
+#ifdef W2C_PHASE_TIMING
+            const long long c0 = clock64();
+#endif
             if (t + STAGES - 2 < KT) {
                 if (more && tap >= 1 && tap <= STAGES - 1) wait_tiles_and_patch(KS2{});
                 else wait_vmcnt<(STAGES - 2) * B_INSTR>();
             } else {
                 wait_vmcnt<0>();
             }
+#ifdef W2C_PHASE_TIMING
+            const long long c1 = clock64();
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef W2C_PHASE_TIMING
+            const long long c2 = clock64();
+#endif
             if (t == 0) dbg_stamp(p, 1);
             if (t + STAGES - 1 < KT) issue_b(wr);
             if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
+#ifdef W2C_PHASE_TIMING
+            const long long c3 = clock64();
+#endif
             load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3));
+#ifdef W2C_PHASE_TIMING
+            asm volatile("" ::: "memory");
+            const long long c4 = clock64();
+#endif
             mfma_all();
+#ifdef W2C_PHASE_TIMING
+            const long long c5 = clock64();
+            ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
+#endif
             rd = (rd + 1 == STAGES) ? 0 : rd + 1;
             wr = (wr + 1 == STAGES) ? 0 : wr + 1;
         }
     }
     __builtin_amdgcn_s_barrier();
     dbg_stamp(p, 2);
+#ifdef W2C_PHASE_TIMING
+    if (p.dbg && (threadIdx.x & 63) == 0) {          // lane 0 of every wave: [WG][wave][5] after the 4 stamps region
+        unsigned long long* o = p.dbg + (1u << 19) + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 5;
+        for (int k = 0; k < 5; ++k) o[k] = (unsigned long long)ph[k];
+    }
+#endif
 
     // ---- epilogue (same contract as the generic kernel; tile row r -> pixel (y0 + r/TW, x0 + r%TW)) ----
     constexpr int CG = BN / 8;
@@ -547,6 +593,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         }
     }
     dbg_stamp(p, 3);
+#endif
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int STAGES>
@@ -651,7 +698,7 @@ int pick_variant(const ConvArgs& a, int groups) {
     if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
         if (Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
-        if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return a.Cin == 64 ? 34 : 31;
+        if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 31;
     }
     if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return 0;
     if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
