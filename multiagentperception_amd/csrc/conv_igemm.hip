@@ -60,6 +60,16 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// Barrier of the LDS pipelines.  A raw s_barrier waits for nothing: the compiler is free to schedule the
+// lgkmcnt wait (and the MFMAs) of this wave's last fragment reads AFTER it, so without the lgkmcnt(0) here a
+// wave could pass the barrier with ds_reads still in flight while another wave's DMA -- issued right after the
+// barrier -- overwrites that ring slot (seen as rare corrupted tiles at 16 waves/CU; tools/_stress_variants.py).
+// The empty asm after it keeps the next step's LDS reads / DMA from being hoisted above the barrier.
+__device__ __forceinline__ void pipeline_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 template <int BM, int BN, int WM, int WN, int BK, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
@@ -213,14 +223,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     for (int t = 0; t < KT; ++t) {
         if (t + STAGES - 2 < KT) wait_vmcnt<(STAGES - 2) * LOADS>();     // tile t (my part) has landed
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                                    // everyone's part landed; tile t-1's buffer is free
+        pipeline_barrier();                                              // everyone's part landed; tile t-1's buffer is free
         if (t == 0) dbg_stamp(p, 1);
         if (t + STAGES - 1 < KT) stage(wr);
         compute(rd);
         rd = (rd + 1 == STAGES) ? 0 : rd + 1;
         wr = (wr + 1 == STAGES) ? 0 : wr + 1;
     }
-    __builtin_amdgcn_s_barrier();    // every wave done reading the ring; reuse LDS for the epilogue
+    // every wave done reading the ring; the epilogue reuses that LDS.  A FENCED barrier: a raw s_barrier does not
+    // stop the compiler from hoisting the staging stores above it (observed as a rare corrupted tile).
+    __syncthreads();
     dbg_stamp(p, 2);
 
     // ---- epilogue 0: residual addresses + loads FIRST (branch-free, clamped), so their HBM latency runs
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 // one barrier per tap, counted vmcnt, patch double-buffered across channel chunks.
 // LDS patch image: one 128-B row per patch pixel, 16-B chunk c of pixel q at c ^ ((q>>1)&7) -- the
 // ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
-template <int TH, int TW, int BN, int WM, int WN, int STAGES>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int BM = TH * TW;
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch0 = smem;
-    char* bring = smem + 2 * PATCH_BYTES;
+    char* bring = smem + PB * PATCH_BYTES;          // PB == 1: single channel chunk (Cin == 64), no patch double buffer
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
     int rd = 0, wr = STAGES - 1, t = 0;
     for (int cc = 0; cc < nchunks; ++cc) {
-        const char* patch = patch0 + (cc & 1) * PATCH_BYTES;
+        const char* patch = patch0 + (PB == 2 ? (cc & 1) : 0) * PATCH_BYTES;
         const bool more = cc + 1 < nchunks;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++t) {
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #ifdef W2C_PHASE_TIMING
             const long long c1 = clock64();
 #endif
-            __builtin_amdgcn_s_barrier();
+            pipeline_barrier();
 #ifdef W2C_PHASE_TIMING
             const long long c2 = clock64();
 #endif
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
             wr = (wr + 1 == STAGES) ? 0 : wr + 1;
         }
     }
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();     // fenced: the epilogue's staging stores must not be hoisted above this barrier
     dbg_stamp(p, 2);
 #ifdef W2C_PHASE_TIMING
     if (p.dbg && (threadIdx.x & 63) == 0) {          // lane 0 of every wave: [WG][wave][5] after the 4 stamps region
@@ -596,13 +608,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #endif
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int STAGES>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
         return W2C_E_ARG;
+    if (PB == 1 && a.Cin != 64) return W2C_E_ARG;
     a.ntm = a.M * (a.H / TH) * (a.W / TW);
     a.ntn = a.Cout / BN;
-    constexpr int ring = 2 * (TH + 2) * (TW + 2) * 128 + STAGES * BN * 128;
+    constexpr int ring = PB * (TH + 2) * (TW + 2) * 128 + STAGES * BN * 128;
     constexpr int epi = TH * TW * (BN + 4) * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS");
@@ -610,12 +623,12 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -683,22 +696,33 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 32: return launch_patch<4, 32, 128, 2, 2, 2>(a, groups, s);
         case 33: return launch_patch<4, 32, 64, 2, 2, 3>(a, groups, s);
         case 34: return launch_patch<8, 16, 64, 2, 2, 2>(a, groups, s);
+        // same 128-pixel / 2-WG-per-CU tiles with 8 waves (wave tile 32 x BN/2): half the DMA instructions per wave
+        case 35: return launch_patch<8, 16, 128, 4, 2, 2>(a, groups, s);
+        case 36: return launch_patch<8, 16, 64, 4, 2, 3>(a, groups, s);
+        case 37: return launch_patch<8, 16, 128, 2, 4, 2>(a, groups, s);
+        // Cin == 64 (one channel chunk): a single patch buffer -> ~39 KB of LDS -> four workgroups per CU
+        case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
+        case 39: return launch_patch<8, 16, 64, 4, 2, 2, 1>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
 
 // Per-layer kernel choice, from the per-layer sweeps of tools/bench_conv.py on MI355X
-// (profiles/r01_b_conv_variant_sweep.txt).  Stride-1 3x3 convs go to the patch-staged kernel with 128-pixel
-// (8x16) tiles and 4 waves -- <= 80 KB of LDS, so two workgroups share a CU -- 128 output channels wide when
-// that still yields >= 256 workgroups, else 64 wide; everything else (stride 2, 1x1, maps narrower than 16
-// pixels) to the generic implicit GEMM, whose tile is chosen to keep >= ~2 workgroups per CU.
+// (profiles/r01_b_conv_variant_sweep.txt; run-to-run noise of single cells is ~+-8 %).  Stride-1 3x3 convs go to
+// the patch-staged kernel with 128-pixel (8x16) tiles sized so that >= 2 workgroups share a CU:
+//   Cin == 64  (layer1: one channel chunk) -> v38: single patch buffer, 39 KB LDS, four workgroups per CU
+//   Cin == 128 (layer2)                    -> v30: 128 output channels per tile, 4 waves
+//   deeper                                  -> v36: 64 output channels per tile, 8 waves, 3-deep weight ring
+// everything else (stride 2, 1x1, maps narrower than 16 pixels) to the generic implicit GEMM, whose tile is chosen
+// to keep >= ~2 workgroups per CU.
 int pick_variant(const ConvArgs& a, int groups) {
     const long rows = a.rows;
     const int Cout = a.Cout;
     if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
-        if (Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
-        if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 31;
+        if (a.Cin == 64 && Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 38;
+        if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
+        if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;
     }
     if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return 0;
     if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
