@@ -136,6 +136,14 @@ int w2c_comm_graph(const float* query, const float* key, const float* wq, const 
                    float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
                    w2c_stream_t stream);
 
+/* Same graph from PROJECTED keys: tproj f32 [N*B, Dq+1] agent-major with tproj[r][j<Dq] = (Wq^T key_r)[j] and
+ * tproj[r][Dq] = key_r . bq.  The engine folds that projection into the key head's last layer at pack time
+ * ((Wq^T W_fc4) h1 + Wq^T b_fc4), so the 1024-d key is never formed and agent-parallel ranks exchange Dq+1 floats
+ * per agent-sample instead of Dk. */
+int w2c_comm_graph_projected(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
+                             float thres, float tie_bias, int q_lo, int q_n,
+                             float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag, w2c_stream_t stream);
+
 /* ---- K7 + a10: attention-weighted fusion (agent.py:276-284) fused with
  * agents2batch (agent.py:1080-1086).
  * v    : bf16 NHWC rows [N*B][hw][v_cstride], agent-major, C channels used

@@ -400,6 +400,19 @@ extern "C" int w2c_comm_graph(const float* query, const float* key, const float*
     return w2c_launch_status();
 }
 
+extern "C" int w2c_comm_graph_projected(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
+                                        float thres, float tie_bias, int q_lo, int q_n,
+                                        float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                                        w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!tproj || !prob || !coef || !action || !nnz_offdiag) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
+    if (q_lo < 0 || q_n <= 0 || q_lo + q_n > N) return W2C_E_ARG;
+    hipLaunchKernelGGL(comm_graph_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, tproj, B, N, Dq,
+                       who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag);
+    return w2c_launch_status();
+}
+
 extern "C" int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, int N, int q_lo, int q_n,
                                int hw, int C, int append_own, uint16_t* out, int out_cstride, w2c_stream_t stream) {
     w2c_clear_error();

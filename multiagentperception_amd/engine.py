@@ -133,19 +133,27 @@ class HeadPlan:
     fc.0 run as ONE wide-K launch (weights stacked along the output dim); fc.2+ReLU+fc.4 of each head
     is one w2c_head_tail_f32 launch (weights packed K-major)."""
 
-    def __init__(self, heads, hw):
+    def __init__(self, heads, hw, key_projection=None):
+        """key_projection = (Wq [Dk,Dq], bq [Dk]) folds the attention's query projection into the FIRST head's
+        (the key head's) last layer: it then emits tproj = [(Wq^T W4) h1 + Wq^T b4 | (bq^T W4) h1 + bq.b4]
+        (Dq+1 values) instead of the Dk-wide key -- exactly what w2c_comm_graph_projected consumes."""
         w0s, b0s = [], []
         self.tails = []
-        for head in heads:
+        for hi, head in enumerate(heads):
             fc = head.fc
             w0 = fc[0].weight.detach().float()
             n_feat = w0.shape[1]
             c = n_feat // hw
             w0s.append(w0.reshape(w0.shape[0], c, hw).permute(0, 2, 1).reshape(w0.shape[0], n_feat))
             b0s.append(fc[0].bias.detach().float())
+            w4, b4 = fc[4].weight.detach().double(), fc[4].bias.detach().double()
+            if hi == 0 and key_projection is not None:
+                wq, bq = key_projection[0].detach().double(), key_projection[1].detach().double()
+                w4 = torch.cat([wq.t() @ w4, (bq @ w4).unsqueeze(0)], 0)            # [Dq+1, 128]
+                b4 = torch.cat([wq.t() @ b4, (bq @ b4).reshape(1)])                  # [Dq+1]
             self.tails.append((w0.shape[0], fc[2].weight.detach().float().t().contiguous(),
                                fc[2].bias.detach().float().contiguous(),
-                               fc[4].weight.detach().float().t().contiguous(), fc[4].bias.detach().float().contiguous()))
+                               w4.float().t().contiguous(), b4.float().contiguous()))
         self.w0 = torch.cat(w0s, 0).contiguous()
         self.b0 = torch.cat(b0s).contiguous()
         self.n_feat = n_feat
@@ -198,13 +206,14 @@ class CommEngine:
 
     def policy_tail(self, sq):
         """policy_net4 conv1..5 + key/query heads on the policy-encoder half of `sq` (agent.py:137-141,
-        1126-1129) -> keys f32 [n*B,Dk], queries f32 [n*B,Dq] or None."""
+        1126-1129) -> PROJECTED keys tproj f32 [n*B,Dq+1] (the attention's Linear(query) folded into the key
+        head, see HeadPlan), queries f32 [n*B,Dq] or None."""
         y = self.policy[0].run(sq, x_ch_off=self.feat)
         for c in self.policy[1:]:
             y = c.run(y)
         hw = y.shape[1] * y.shape[2]
         if self.heads is None:
-            self.heads = HeadPlan([h for h in self._model_heads if h is not None], hw)
+            self.heads = HeadPlan([h for h in self._model_heads if h is not None], hw, key_projection=(self.wq, self.bq))
         outs = self.heads.run(y)
         return outs[0], (outs[1] if len(outs) > 1 else None)
 
@@ -218,8 +227,8 @@ class CommEngine:
     def graph_and_low(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
         """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decoder convs
         (everything up to the low-resolution logits)."""
-        prob, coef, action, nnz = ops.comm_graph(querys_local, keys_all, self.wq, self.bq, B, N, self.who, mode,
-                                                 q_lo=q_lo, q_n=q_n)
+        prob, coef, action, nnz = ops.comm_graph_projected(querys_local, keys_all, B, N, self.who, mode,
+                                                           q_lo=q_lo, q_n=q_n)
         fused = ops.fuse_values(sq_all, self.feat, coef, B, N, q_lo, q_n, append_own=self.who)
         return self.decoder.low_logits(fused), prob, action, nnz
 

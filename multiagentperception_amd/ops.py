@@ -211,6 +211,23 @@ def comm_graph(query, key, wq, bq, B, N, who, mode, thres=0.2, tie_bias=0.001, q
     return prob, coef, action, nnz
 
 
+def comm_graph_projected(query, tproj, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None):
+    """Like comm_graph, from projected keys tproj [N*B, Dq+1] (see w2c_comm_graph_projected)."""
+    dev = _need_gpu(query, tproj)
+    Dq = tproj.shape[1] - 1
+    if q_n is None:
+        q_n = N - q_lo
+    prob = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
+    coef = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
+    action = torch.empty((B, q_n), dtype=torch.int64, device=dev)
+    nnz = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_comm_graph_projected(_p(query), _p(tproj), B, N, Dq, 1 if who else 0, MODE_IDS[mode],
+                                                     float(thres), float(tie_bias), q_lo, q_n, _p(prob), _p(coef),
+                                                     _p(action), _p(nnz), _stream(dev)), "w2c_comm_graph_projected")
+    return prob, coef, action, nnz
+
+
 def fuse_values(v, v_ch, coef, B, N, q_lo, q_n, append_own=False, out=None):
     """v: bf16 NHWC [N*B,h,w,vcs] (first v_ch channels are the value map) -> [q_n*B,h,w,C or 2C]."""
     dev = _need_gpu(v, coef, out)

@@ -5,7 +5,9 @@ train.py:177).  SURVEY.md section 8e.
 
 Rank r owns agents [r*n_loc, (r+1)*n_loc).  Encoders and policy net are per-image with shared
 (replicated) eval-mode weights, so they need no communication; the communication graph needs
-every agent's K and V (agent.py:1155); queries stay local; each rank fuses + decodes only its own
+every agent's K and V (agent.py:1155) -- K travels as the PROJECTED key (Wq^T k | k.bq: Dq+1 = 33 floats per
+agent-sample instead of 1024, the attention's Linear(query) is folded into the key head at pack time);
+queries stay local; each rank fuses + decodes only its own
 query agents.  xGMI is a point-to-point full mesh (7 links x ~153 GB/s per GPU): the V shard
 (cfg 3: 2 MiB, cfg 4: 4 MiB bf16) is pushed once to each peer, ~14-27 us, and is issued
 asynchronously as soon as the trunk's squeezer output exists so it overlaps the policy-net tail

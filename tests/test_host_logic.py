@@ -147,3 +147,26 @@ def test_train_mode_stock_op_path_keeps_reference_return_tuple():
     assert pred.shape == (4, 11, 128, 128) and prob.shape == (2, 2, 2) and action.shape == (2, 2) and nconn == 1
     pred.mean().backward()
     assert m.decoder.output_decoder.pred[2].weight.grad is not None
+
+
+def test_query_projection_folded_into_key_head_is_the_same_algebra():
+    """HeadPlan(key_projection=(Wq,bq)): the key head's fused last layer emits [Wq^T key | bq.key] (Dq+1 values)."""
+    from multiagentperception_amd import engine
+    from multiagentperception_amd.models import blocks
+    gen = torch.Generator().manual_seed(3)
+    head = blocks.km_generator(out_size=1024, input_feat_sz=128 / 32)     # n_feat = 256
+    qhead = blocks.km_generator(out_size=32, input_feat_sz=128 / 32)
+    filler.apply_to_module(head)
+    filler.apply_to_module(qhead)
+    wq = torch.randn(1024, 32, generator=gen) * 0.1
+    bq = torch.randn(1024, generator=gen) * 0.05
+    hp = engine.HeadPlan([head, qhead], hw=1, key_projection=(wq, bq))
+    h1 = torch.relu(torch.randn(5, 128, generator=gen))
+    key = F.linear(h1, head.fc[4].weight, head.fc[4].bias)               # what the reference's key_net would emit
+    want = torch.cat([key @ wq, (key @ bq).unsqueeze(1)], 1)             # [5, 33]
+    k1, w1t, b1, w2t, b2 = hp.tails[0]
+    got = h1 @ w2t + b2
+    assert tuple(w2t.shape) == (128, 33)
+    np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), atol=2e-5, rtol=1e-5)
+    # the query head is untouched
+    np.testing.assert_array_equal(hp.tails[1][3].numpy(), qhead.fc[4].weight.detach().t().contiguous().numpy())

@@ -318,6 +318,27 @@ def test_comm_graph_matches_reference_attention(who, mode, B, N, has_q):
         np.testing.assert_array_equal(nnz.cpu().numpy(), rn.numpy())
 
 
+def test_comm_graph_projected_equals_comm_graph():
+    """w2c_comm_graph_projected on tproj = [Wq^T key | key.bq] == w2c_comm_graph on the raw keys."""
+    from multiagentperception_amd import ops
+    B, N, Dq, Dk = 3, 5, 32, 1024
+    gen = torch.Generator().manual_seed(9)
+    key = torch.randn(N * B, Dk, generator=gen) * 0.3
+    query = torch.randn(N * B, Dq, generator=gen)
+    wq = torch.randn(Dk, Dq, generator=gen) * 0.1
+    bq = torch.randn(Dk, generator=gen) * 0.05
+    tproj = torch.cat([key.double() @ wq.double(), (key.double() @ bq.double()).unsqueeze(1)], 1).float()
+    for who in (False, True):
+        for mode in ("softmax", "argmax_test", "activated"):
+            a = ops.comm_graph(query.to(_dev()), key.to(_dev()), wq.to(_dev()), bq.to(_dev()), B, N, who, mode)
+            b = ops.comm_graph_projected(query.to(_dev()), tproj.to(_dev()), B, N, who, mode)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), atol=2e-6)
+            np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), atol=2e-6)
+            np.testing.assert_array_equal(b[2].cpu().numpy(), a[2].cpu().numpy())
+            np.testing.assert_array_equal(b[3].cpu().numpy(), a[3].cpu().numpy())
+
+
 def test_comm_graph_query_slice_equals_full():
     """agent-parallel ranks ask for a slice of the query agents; columns must equal the full call."""
     from multiagentperception_amd import ops

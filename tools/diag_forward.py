@@ -71,12 +71,14 @@ def main():
     V = sq.float().cpu()[..., :512].permute(0, 3, 1, 2)                 # agent-major [M,512,h,w]
     rV = orc.agents2batch(ex["val_mat"])
     rK = orc.agents2batch(ex["key_mat"])
+    wq, bq = sd["attention_net.linear.weight"], sd["attention_net.linear.bias"]
+    rK = torch.cat([rK @ wq, (rK @ bq).unsqueeze(1)], 1)               # the engine emits PROJECTED keys [Wq^T k | k.bq]
     rQ = orc.agents2batch(ex["query_mat"])
     print("[HIP]                   V rel %.2e  keys rel %.2e  query rel %.2e  P maxabs %.2e  logits rel %.2e  low rel %.2e" % (
         rel(V, rV), rel(keys.cpu(), rK), rel(querys.cpu(), rQ), float((prob.cpu() - rprob).abs().max()),
         rel(pred.cpu(), rpred), rel(low.cpu()[..., :11].permute(0, 3, 1, 2), ex["low_logits"])))
     print("[HIP vs emulated]       V rel %.2e  keys rel %.2e  P maxabs %.2e  logits rel %.2e" % (
-        rel(V, orc.agents2batch(eex["val_mat"])), rel(keys.cpu(), orc.agents2batch(eex["key_mat"])),
+        rel(V, orc.agents2batch(eex["val_mat"])), rel(keys.cpu(), torch.cat([orc.agents2batch(eex["key_mat"]) @ wq, (orc.agents2batch(eex["key_mat"]) @ bq).unsqueeze(1)], 1)),
         float((prob.cpu() - eprob).abs().max()), rel(pred.cpu(), epred)))
     agree = float((pred.cpu().argmax(1) == rpred.argmax(1)).float().mean())
     print("argmax agreement HIP vs oracle %.4f ; emulated vs oracle %.4f" % (
