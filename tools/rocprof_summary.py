@@ -25,7 +25,7 @@ def main():
     if "--forward" in sys.argv:
         ks = list(c.execute("select name, start, duration, grid_x, grid_y, lds_size, vgpr_count, accum_vgpr_count "
                             "from kernels order by start"))
-        idx = [i for i, r in enumerate(ks) if "stem_kernel" in r[0]]
+        idx = [i for i, r in enumerate(ks) if "stem_" in r[0]]
         if len(idx) >= 5:
             s, e = idx[-5], idx[-4]
             print("\n# one forward (launch order), a step inside the timed region")
