@@ -59,6 +59,15 @@ int w2c_stem_conv7x7_bn_relu_maxpool(const float* x, int B, int N, int H, int W,
                                      const uint16_t* w, const float* scale, const float* shift, int Cout,
                                      uint16_t* y, w2c_stream_t stream);
 
+/* ---- SURVEY 8f row 4 (input side): the same fused stem fed with the camera frames as the reference's loader reads them
+ * -- u8 RGB [B, N, H, W, 3] -- applying the loader's transform (airsim_loader.py:521-527: RGB->BGR,
+ * float64 (v - mean)/255, cast to f32) on the fly, bit-identically to feeding the transformed f32 frames.
+ * mean_b/g/r : the loader's BGR means (103.939, 116.779, 123.68). */
+int w2c_stem_u8_conv7x7_bn_relu_maxpool(const uint8_t* frames, double mean_b, double mean_g, double mean_r,
+                                        int B, int N, int H, int W,
+                                        const uint16_t* w, const float* scale, const float* shift, int Cout,
+                                        uint16_t* y, w2c_stream_t stream);
+
 /* ---- K1b: maxpool 3x3 s2 p1 (backbone.py:66 via resnet.maxpool), bf16 NHWC.
  * x [M, H, W, C] -> y [M, H/2, W/2, C]; C multiple of 8. */
 int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, w2c_stream_t stream);
@@ -159,6 +168,12 @@ int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, 
  * out : f32 NCHW [M, n_classes, 32h, 32w] */
 int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                             float* out, w2c_stream_t stream);
+
+/* ---- SURVEY 8f row 4 (output side): K9 fused with the evaluator's class argmax (trainer.py:804
+ * `outputs.data.max(1)[1]`): labels u8 [M, 32h, 32w] = argmax over classes of the bilinear x32 upsample of `low`
+ * (identical arithmetic to w2c_upsample_bilinear32, lowest index on ties); the f32 logits are never written. */
+int w2c_upsample32_argmax(const float* low, int M, int h, int w, int low_cstride, int n_classes,
+                          uint8_t* labels, w2c_stream_t stream);
 
 /* ---- helpers at the boundary ---- */
 /* f32 NCHW [M,C,H,W] -> bf16 NHWC [M,H,W,cstride] (channels [0,C)); used by tests and the

@@ -22,6 +22,8 @@ SIGNATURES = {
     "w2c_device_arch": [_c.c_char_p, _i],
     "w2c_stem_conv7x7_bn_relu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "w2c_stem_conv7x7_bn_relu_maxpool": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "w2c_stem_u8_conv7x7_bn_relu_maxpool": [_vp, _c.c_double, _c.c_double, _c.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _i,
+                                            _vp, _vp],
     "w2c_maxpool3x3s2": [_vp, _i, _i, _i, _i, _vp, _vp],
     "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
     "w2c_conv_igemm_bf16_variant": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
@@ -33,6 +35,7 @@ SIGNATURES = {
     "w2c_comm_graph_projected": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "w2c_fuse_values": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "w2c_upsample32_argmax": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_nchw_f32_to_nhwc_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_nhwc_bf16_to_nchw_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
 }

@@ -161,8 +161,13 @@ constexpr int FP_ROWS = 23;        // input rows for 9 conv rows: 2*8 + 7
 constexpr int FP_COLS = 72;
 constexpr int FP_BYTES = FP_ROWS * FP_COLS * 8;
 
-template <int COUT>
-__global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict__ x, int B, int N, int H, int W,
+// U8 = true: `x` holds the camera frames as the reference's loader reads them -- u8 RGB, [B][N][H][W][3] -- and the
+// loader's transform (airsim_loader.py:521-527: RGB->BGR, float64 (v - mean)/255, cast to f32) is applied while the
+// patch is staged, in double precision, so the bf16 patch is bit-identical to staging the transformed f32 frames.
+struct FrameMean { double m[3]; };   // BGR means
+
+template <int COUT, bool U8>
+__global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
                                                         const uint16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict_
     const int img = blockIdx.y;
     const int agent = img / B, b = img - agent * B;
     const int oy0 = blockIdx.x * 8;
-    const float* xin = x + ((size_t)b * 3 * N + 3 * agent) * H * W;
+    const float* xin = U8 ? nullptr : reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
+    const uint8_t* xin8 = U8 ? reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3 : nullptr;
 
     bf16x8_t wf[7][2];
     {
@@ -216,7 +222,11 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict_
             const int iy = iy_base + r, ix = ix_base + c;
             const bool ok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
             const size_t o = ok ? (size_t)iy * W + ix : 0;
-            pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];   // raw, masked at store
+            if constexpr (U8) {       // network channel c (BGR) = frame channel 2-c (RGB); raw bytes, converted at store
+                pv[f][0] = (float)xin8[o * 3 + 2]; pv[f][1] = (float)xin8[o * 3 + 1]; pv[f][2] = (float)xin8[o * 3];
+            } else {
+                pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];   // raw, masked at store
+            }
             pmask = ok ? (pmask | (1u << f)) : (pmask & ~(1u << f));
         }
     };
@@ -225,8 +235,14 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float* __restrict_
         for (int f = 0; f < FILL; ++f) {
             const int pidx = tid + f * 512;
             const bool ok = (pmask >> f) & 1u;
+            float v0 = pv[f][0], v1 = pv[f][1], v2 = pv[f][2];
+            if constexpr (U8) {
+                v0 = (float)(((double)v0 - mean.m[0]) / 255.0);
+                v1 = (float)(((double)v1 - mean.m[1]) / 255.0);
+                v2 = (float)(((double)v2 - mean.m[2]) / 255.0);
+            }
             if (pidx < FP_ROWS * FP_COLS)
-                patch[pidx] = ok ? make_uint2(pack_bf16x2(pv[f][0], pv[f][1]), pack_bf16x2(pv[f][2], 0.f)) : make_uint2(0u, 0u);
+                patch[pidx] = ok ? make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f)) : make_uint2(0u, 0u);
         }
     };
     auto stg_addr = [&](int row, int col, int chunk) -> char* {
@@ -384,20 +400,20 @@ extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int
     return W2C_E_ARG;
 }
 
-template <int COUT>
-static int launch_stem_pool(const float* x, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+template <int COUT, bool U8>
+static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                      const float* shift, uint16_t* y, hipStream_t s) {
     constexpr int lds = FP_BYTES + 9 * 33 * COUT * 2;
     static unsigned long long attr_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT, U8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid((H / 2) / 8, N * B);
-    hipLaunchKernelGGL((stem_pool_kernel<COUT>), grid, dim3(512), lds, s, x, B, N, H, W, w, scale, shift, y);
+    hipLaunchKernelGGL((stem_pool_kernel<COUT, U8>), grid, dim3(512), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
     return w2c_launch_status();
 }
 
@@ -408,8 +424,23 @@ extern "C" int w2c_stem_conv7x7_bn_relu_maxpool(const float* x, int B, int N, in
     if (!x || !w || !scale || !shift || !y) return W2C_E_ARG;
     if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 64) != 0) return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (Cout == 128) return launch_stem_pool<128>(x, B, N, H, W, w, scale, shift, y, s);
-    if (Cout == 64) return launch_stem_pool<64>(x, B, N, H, W, w, scale, shift, y, s);
+    FrameMean none = {{0.0, 0.0, 0.0}};
+    if (Cout == 128) return launch_stem_pool<128, false>(x, none, B, N, H, W, w, scale, shift, y, s);
+    if (Cout == 64) return launch_stem_pool<64, false>(x, none, B, N, H, W, w, scale, shift, y, s);
+    return W2C_E_ARG;
+}
+
+extern "C" int w2c_stem_u8_conv7x7_bn_relu_maxpool(const uint8_t* frames, double mean_b, double mean_g, double mean_r,
+                                                   int B, int N, int H, int W,
+                                                   const uint16_t* w, const float* scale, const float* shift, int Cout,
+                                                   uint16_t* y, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!frames || !w || !scale || !shift || !y) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 64) != 0) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    FrameMean mean = {{mean_b, mean_g, mean_r}};
+    if (Cout == 128) return launch_stem_pool<128, true>(frames, mean, B, N, H, W, w, scale, shift, y, s);
+    if (Cout == 64) return launch_stem_pool<64, true>(frames, mean, B, N, H, W, w, scale, shift, y, s);
     return W2C_E_ARG;
 }
 

@@ -12,6 +12,13 @@
 
 namespace {
 
+// one definition of the lerp (explicit fma placement, not left to -ffp-contract) shared by K9 and its argmax fusion
+__device__ __forceinline__ float lerp2d(float ly0, float ly1, float lx0, float lx1, float p00, float p01, float p10, float p11) {
+    const float top = __builtin_fmaf(lx1, p01, lx0 * p00);
+    const float bot = __builtin_fmaf(lx1, p11, lx0 * p10);
+    return __builtin_fmaf(ly1, bot, ly0 * top);
+}
+
 __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
                                                          float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,10 +47,56 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
             const int x0 = (int)sx;
             const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
             const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-            o[e] = ly0 * (lx0 * plane[y0 * w + x0] + lx1 * plane[y0 * w + x1]) +
-                   ly1 * (lx0 * plane[y1 * w + x0] + lx1 * plane[y1 * w + x1]);
+            o[e] = lerp2d(ly0, ly1, lx0, lx1, plane[y0 * w + x0], plane[y0 * w + x1], plane[y1 * w + x0], plane[y1 * w + x1]);
         }
         *reinterpret_cast<f32x4_t*>(obase + (size_t)ry * W + gx * 4) = o;
+    }
+}
+
+// K9 + the evaluator's class argmax (trainer.py:804 `outputs.data.max(1)[1]`) fused: the full-resolution f32
+// logits (231 MB at cfg 2) are never written -- only one u8 label per pixel (5 MB).  Same source-index and lerp
+// arithmetic as upsample32_kernel, so labels == argmax over classes of its output, bit for bit; ties keep the
+// lowest class index.  Workgroup = (32-row band, image): the image's whole low-res logit block sits in LDS.
+__global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
+                                                                uint8_t* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* blk = reinterpret_cast<float*>(smem);       // [ncls][h][w]
+    const int H = h * 32, W = w * 32;
+    const int band = blockIdx.x, m = blockIdx.y;
+    for (int i = threadIdx.x; i < ncls * h * w; i += 256) {
+        const int c = i / (h * w), p = i - c * (h * w);
+        blk[i] = low[((size_t)m * h * w + p) * lcs + c];
+    }
+    __syncthreads();
+    const int xq = W >> 2;
+    uint8_t* obase = labels + ((size_t)m * H + (size_t)band * 32) * W;
+    for (int id = threadIdx.x; id < 32 * xq; id += 256) {
+        const int ry = id / xq, gx = id - ry * xq;
+        const int oy = band * 32 + ry;
+        float sy = (oy + 0.5f) * 0.03125f - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ox = gx * 4 + e;
+            float sx = (ox + 0.5f) * 0.03125f - 0.5f;
+            sx = sx < 0.f ? 0.f : sx;
+            const int x0 = (int)sx;
+            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            float best = -INFINITY;
+            int bi = 0;
+            for (int c = 0; c < ncls; ++c) {
+                const float* pl = blk + c * h * w;
+                const float v = lerp2d(ly0, ly1, lx0, lx1, pl[y0 * w + x0], pl[y0 * w + x1], pl[y1 * w + x0], pl[y1 * w + x1]);
+                if (v > best) { best = v; bi = c; }
+            }
+            packed |= (uint32_t)bi << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W + gx * 4) = packed;
     }
 }
 
@@ -85,6 +138,18 @@ extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, in
     if ((size_t)h * w * 4 > 64 * 1024) return W2C_E_ARG;
     hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), (size_t)h * w * 4,
                        reinterpret_cast<hipStream_t>(stream), low, h, w, low_cstride, n_classes, out);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_upsample32_argmax(const float* low, int M, int h, int w, int low_cstride, int n_classes,
+                                     uint8_t* labels, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!low || !labels || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || n_classes > 255 || low_cstride < n_classes)
+        return W2C_E_ARG;
+    const size_t lds = (size_t)n_classes * h * w * 4;
+    if (lds > 64 * 1024) return W2C_E_ARG;
+    hipLaunchKernelGGL(upsample32_argmax_kernel, dim3(h, M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       low, h, w, low_cstride, n_classes, labels);
     return w2c_launch_status();
 }
 

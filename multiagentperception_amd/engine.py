@@ -110,8 +110,10 @@ class TrunkPlan:
         self.squeezer = ConvPlan([s[0] for s in sq], [s[1] for s in sq], relu=True)
 
     def stem(self, x, n_agents, out=None):
-        """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/4, W/4, G*64]: conv1+bn1+relu+maxpool of all trunks, fused
-        (agent-major)."""
+        """x f32 [B, 3N, H, W] (or u8 RGB frames [B, N, H, W, 3]) -> bf16 NHWC
+        [N*B, H/4, W/4, G*64]: conv1+bn1+relu+maxpool of all trunks, fused (agent-major)."""
+        if x.dtype == torch.uint8:
+            return ops.stem_u8_conv7x7_bn_relu_maxpool(x, self.stem_w, self.stem_scale, self.stem_shift, out=out)
         return ops.stem_conv7x7_bn_relu_maxpool(x, n_agents, self.stem_w, self.stem_scale, self.stem_shift, out=out)
 
     def after_stem(self, p):
@@ -237,13 +239,16 @@ class CommEngine:
         return ops.upsample_bilinear32(low, self.n_classes), prob, action, nnz, low
 
     # ---- whole single-GPU forward, optionally replayed from a captured HIP graph ------------------
-    def forward_local(self, x, B, N, mode, use_graph=False):
-        """-> pred f32 [N*B,n_cls,H,W] (fresh tensor), prob [B,N,N], action [B,N], nnz [B]."""
+    def forward_local(self, x, B, N, mode, use_graph=False, labels=False):
+        """-> pred f32 [N*B,n_cls,H,W] (fresh tensor; or u8 class labels [N*B,H,W] when labels=True: the
+        evaluator's argmax fused into the upsample), prob [B,N,N], action [B,N], nnz [B]."""
+        finish = (lambda low: ops.upsample32_argmax(low, self.n_classes)) if labels else \
+                 (lambda low: ops.upsample_bilinear32(low, self.n_classes))
         if not use_graph:
             sq, keys, querys = self.encode(x, N)
-            pred, prob, action, nnz, _ = self.graph_and_decode(sq, keys, querys, B, N, 0, N, mode)
-            return pred, prob, action, nnz
-        key = (tuple(x.shape), mode)
+            low, prob, action, nnz = self.graph_and_low(sq, keys, querys, B, N, 0, N, mode)
+            return finish(low), prob, action, nnz
+        key = (tuple(x.shape), str(x.dtype), mode)
         entry = self._graphs.get(key)
         if entry is None:
             entry = self._capture(x, B, N, mode)
@@ -251,7 +256,7 @@ class CommEngine:
         s0, graph, low, prob, action, nnz = entry
         self.trunk.stem(x, N, out=s0)                       # eager: reads the caller's tensor
         graph.replay()                                      # maxpool ... decoder convs (45 launches)
-        pred = ops.upsample_bilinear32(low, self.n_classes)  # eager: writes the caller-owned output
+        pred = finish(low)                                   # eager: writes the caller-owned output
         return pred, prob.clone(), action.clone(), nnz.clone()
 
     def _capture(self, x, B, N, mode):

@@ -41,14 +41,23 @@ class RunningScore:
                 "class_iou": iu, "bandwidth": (self.total_bandw / self.count) if self.count else 0.0}
 
 
-def evaluate_batches(model, batches, device, inference_mode="activated", n_classes=11, mo_flag=True):
-    """batches: iterable of (images_list[N] of [B,3,H,W], labels_list[N] of [B,H,W])."""
+def evaluate_batches(model, batches, device, inference_mode="activated", n_classes=11, mo_flag=True, fused_labels=False):
+    """batches: iterable of (images_list[N] of [B,3,H,W], labels_list[N] of [B,H,W]).
+    fused_labels=True uses model.forward_labels (class argmax fused into the upsample: 5 MB of u8 labels cross PCIe
+    instead of 231 MB of f32 logits); `images_list` may then also be ONE u8 RGB frame tensor [B,N,H,W,3]."""
     score = RunningScore(n_classes)
     model.eval()
     model.to(device)
     for images_list, labels_list in batches:
-        images = torch.cat(tuple(images_list), dim=1)                       # trainer.py:793
         labels = torch.cat(tuple(labels_list), dim=0) if mo_flag else labels_list[0]
+        if fused_labels:
+            images = images_list if torch.is_tensor(images_list) else torch.cat(tuple(images_list), dim=1)
+            pred_dev, _, _, band_w = model.forward_labels(images.to(device), MO_flag=mo_flag, inference=inference_mode)
+            pred = pred_dev.cpu().numpy().astype(np.int64)
+            score.update(labels.numpy(), pred)
+            score.update_bandw(band_w)
+            continue
+        images = torch.cat(tuple(images_list), dim=1)                       # trainer.py:793
         outputs, _, _, band_w = model(images.to(device), training=False, MO_flag=mo_flag, inference=inference_mode)
         pred = outputs.max(1)[1].cpu().numpy()                              # trainer.py:804
         score.update(labels.numpy(), pred)

@@ -140,6 +140,25 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
             num_connect = int(nnz.sum().item()) / (self.agent_num * B)                 # agent.py:1056,1076
         return pred, prob, action, num_connect
 
+    def forward_labels(self, inputs, MO_flag=True, inference="activated"):
+        """Evaluator fast path (not part of the reference API): same forward, but
+        `inputs` may also be the raw camera frames (u8 RGB [B, N, H, W, 3], loader transform fused into the
+        stem) and the first return value is the u8 class-label map [N*B, H, W] (= outputs.max(1)[1] of
+        forward(), trainer.py:804) instead of 231 MB of f32 logits.  eval() only."""
+        if self.training:
+            raise W2CError("forward_labels is an eval-only (HIP) path; call model.eval()")
+        if not MO_flag:
+            raise W2CError("MO_flag=False is not supported (see forward)")
+        if inference not in _INFERENCE_MODES:
+            raise ValueError("Incorrect inference mode")
+        eng = self._engine_for(inputs, _engine.CommEngine)
+        B, N = inputs.shape[0], self.agent_num
+        with torch.no_grad():
+            x = inputs.contiguous() if inputs.dtype == torch.uint8 else inputs.contiguous().float()
+            labels, prob, action, nnz = eng.forward_local(x, B, N, inference, use_graph=self.use_hip_graph, labels=True)
+        num_connect = self.agent_num - 1 if inference == "softmax" else int(nnz.sum().item()) / (self.agent_num * B)
+        return labels, prob, action, num_connect
+
     # ---- train-mode path: stock PyTorch ops + autograd (outside the accelerated scope) ------
     def _forward_train_stock_ops(self, inputs, training, MO_flag, inference):
         if not training:

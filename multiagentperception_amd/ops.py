@@ -110,6 +110,26 @@ def stem_conv7x7_bn_relu_maxpool(x, n_agents, w_packed, scale, shift, out=None):
     return out
 
 
+FRAME_MEAN_BGR = (103.939, 116.779, 123.68)          # airsimLoader.mean (airsim_loader.py)
+
+
+def stem_u8_conv7x7_bn_relu_maxpool(frames, w_packed, scale, shift, mean_bgr=FRAME_MEAN_BGR, out=None):
+    """frames u8 RGB [B,N,H,W,3] -> bf16 NHWC [N*B, H/4, W/4, Cout]; loader transform fused (see the C header)."""
+    dev = _need_gpu(frames, w_packed, scale, shift, out)
+    if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[4] != 3:
+        raise W2CError("stem_u8: expected u8 [B, N, H, W, 3], got %s %s" % (tuple(frames.shape), frames.dtype))
+    B, N, H, W, _ = frames.shape
+    cout = scale.numel()
+    if out is None:
+        out = torch.empty((N * B, H // 4, W // 4, cout), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_stem_u8_conv7x7_bn_relu_maxpool(_p(frames), float(mean_bgr[0]), float(mean_bgr[1]),
+                                                                float(mean_bgr[2]), B, N, H, W, _p(w_packed), _p(scale),
+                                                                _p(shift), cout, _p(out), _stream(dev)),
+              "w2c_stem_u8_conv7x7_bn_relu_maxpool")
+    return out
+
+
 def maxpool3x3s2(x, out=None):
     dev = _need_gpu(x, out)
     M, H, W, C = x.shape
@@ -250,6 +270,17 @@ def upsample_bilinear32(low, n_classes, out=None):
     with torch.cuda.device(dev):
         check(_native.lib().w2c_upsample_bilinear32(_p(low), M, h, w, lcs, n_classes, _p(out), _stream(dev)),
               "w2c_upsample_bilinear32")
+    return out
+
+
+def upsample32_argmax(low, n_classes):
+    """low f32 NHWC [M,h,w,lcs] -> u8 labels [M,32h,32w] = argmax_c of the bilinear x32 upsample."""
+    dev = _need_gpu(low)
+    M, h, w, lcs = low.shape
+    out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_upsample32_argmax(_p(low), M, h, w, lcs, n_classes, _p(out), _stream(dev)),
+              "w2c_upsample32_argmax")
     return out
 
 

@@ -125,10 +125,25 @@ def apply_to_module(module):
     return module
 
 
+def synthetic_frames_u8(batch, agents, height, width, seed):
+    """The same frames as synthetic_frames BEFORE the loader transform: u8 RGB [B, N, H, W, 3], i.e.
+    synthetic_frames == transform(synthetic_frames_u8) with transform = airsim_loader.py:521-527."""
+    bgr = _synthetic_u8_bgr(batch, agents, height, width, seed)            # [B, N, 3(BGR), H, W]
+    return np.ascontiguousarray(bgr[:, :, ::-1].transpose(0, 1, 3, 4, 2)).astype(np.uint8)
+
+
 def synthetic_frames(batch, agents, height, width, seed):
     """AirSim-MAP-shaped input [B, 3N, H, W] float32 (airsim_loader.py:515-540):
     u8 BGR frame, minus mean [103.939, 116.779, 123.68], / 255.  A smooth
     low-frequency field plus hashed noise, regenerable anywhere from the seed."""
+    u8 = _synthetic_u8_bgr(batch, agents, height, width, seed)
+    mean = np.array([103.939, 116.779, 123.68], dtype=np.float64)[None, None, :, None, None]
+    img = ((u8 - mean) / 255.0).astype(np.float32)
+    return img.reshape(batch, agents * 3, height, width)
+
+
+def _synthetic_u8_bgr(batch, agents, height, width, seed):
+    """float64 array of integer values in [0, 255], [B, N, 3 (BGR), H, W]."""
     n = batch * agents * 3 * height * width
     noise = uniform_pm1("frames", n, salt=seed).reshape(batch, agents, 3, height, width)
     yy = np.arange(height, dtype=np.float64)[:, None] / height
@@ -147,10 +162,7 @@ def synthetic_frames(batch, agents, height, width, seed):
     off = 127.5 + 70.0 * st[..., 0, None, None, None]
     amp = 50.0 + 40.0 * st[..., 1, None, None, None]
     nz = 25.0 + 20.0 * st[..., 2, None, None, None]
-    u8 = np.clip(np.floor(off + amp * field + nz * noise), 0, 255)
-    mean = np.array([103.939, 116.779, 123.68], dtype=np.float64)[None, None, :, None, None]
-    img = ((u8 - mean) / 255.0).astype(np.float32)
-    return img.reshape(batch, agents * 3, height, width)
+    return np.clip(np.floor(off + amp * field + nz * noise), 0, 255)
 
 
 def synthetic_labels(rows, height, width, seed, n_classes=11):

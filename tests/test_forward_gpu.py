@@ -153,6 +153,34 @@ def test_evaluate_call_sequence_harness():
     assert score["bandwidth"] == n - 1
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_evaluator_path_u8_frames_to_label_maps(graph):
+    """forward_labels on the raw u8 camera frames == argmax of forward() on the loader-transformed
+    frames, exactly; and the harness scores identically through either path."""
+    from multiagentperception_amd.harness import evaluate_batches
+    case = CASES[0]
+    model, _ = _build(case)
+    model.use_hip_graph = graph
+    b, n, s = case["batch"], case["agent_num"], case["size"]
+    x = torch.from_numpy(filler.synthetic_frames(b, n, s, s, case["seed"])).cuda()
+    u8 = torch.from_numpy(filler.synthetic_frames_u8(b, n, s, s, case["seed"])).cuda()
+    for mode in ("softmax", "activated"):
+        ref = model(x, training=False, MO_flag=True, inference=mode)
+        for inp in (x, u8):
+            lab, prob, action, bw = model.forward_labels(inp, inference=mode)
+            assert lab.dtype == torch.uint8
+            assert torch.equal(lab.long(), ref[0].max(1)[1])
+            assert torch.equal(prob, ref[1]) and torch.equal(action, ref[2]) and bw == ref[3]
+    lab = filler.synthetic_labels(b * n, s, s, case["seed"])
+    labels_list = [torch.from_numpy(lab[i * b:(i + 1) * b]) for i in range(n)]
+    images_list = [x[:, 3 * i:3 * i + 3].cpu() for i in range(n)]
+    s1 = evaluate_batches(model, [(images_list, labels_list)], device="cuda:0", inference_mode="softmax")
+    s2 = evaluate_batches(model, [(u8.cpu(), labels_list)], device="cuda:0", inference_mode="softmax", fused_labels=True)
+    assert s1.keys() == s2.keys()
+    for k in s1:
+        np.testing.assert_array_equal(np.asarray(s1[k]), np.asarray(s2[k]))
+
+
 def test_hip_graph_replay_equals_eager_bit_for_bit():
     """W2C_HIP_GRAPH path: the captured middle of the forward must reproduce the eager launches exactly,
     on the capture input AND on a different input of the same shape (static-buffer plumbing)."""

@@ -390,6 +390,41 @@ def test_upsample_matches_interpolate(M, h, w):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-6, rtol=1e-6)
 
 
+@pytest.mark.parametrize("M,h,w", [(3, 4, 4), (20, 16, 16), (1, 8, 5)])
+def test_upsample_argmax_equals_argmax_of_upsample(M, h, w):
+    """SURVEY 8f row 4 (trainer.py:804): fused labels == outputs.max(1)[1] of the unfused K9 output, bit for bit."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(M + h + w)
+    lowd = torch.randn(M, h, w, 32, generator=gen).to(_dev())
+    lowd[..., 11:] = 100.0                                          # padding channels must never win
+    full = ops.upsample_bilinear32(lowd, 11)
+    lab = ops.upsample32_argmax(lowd, 11)
+    torch.cuda.synchronize()
+    assert lab.dtype == torch.uint8 and lab.shape == (M, 32 * h, 32 * w)
+    assert torch.equal(lab.long(), full.max(1)[1])
+
+
+@pytest.mark.parametrize("cout,B,N,H,W", [(128, 2, 3, 64, 128), (64, 1, 2, 128, 128), (128, 1, 1, 16, 64)])
+def test_u8_frame_stem_equals_f32_stem_on_transformed_frames(cout, B, N, H, W):
+    """SURVEY 8f row 4 (airsim_loader.py:521-527): RGB->BGR, float64 (v-mean)/255, f32 cast fused into the stem ==
+    the stem fed with the loader-transformed f32 frames, bit for bit."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(cout + H)
+    frames = torch.randint(0, 256, (B, N, H, W, 3), generator=gen, dtype=torch.uint8)
+    mean = torch.tensor(ops.FRAME_MEAN_BGR, dtype=torch.float64)
+    bgr = frames.flip(-1).to(torch.float64)
+    x = ((bgr - mean) / 255.0).to(torch.float32).permute(0, 1, 4, 2, 3).reshape(B, 3 * N, H, W).contiguous()
+    wp = torch.zeros(cout, 7, 8, 4)
+    wp[:, :, :7, :3] = torch.randn(cout, 7, 7, 3, generator=gen) * (2.0 / 147) ** 0.5
+    wd = wp.reshape(cout, 224).to(BF16).to(_dev())
+    scale = (torch.rand(cout, generator=gen) + 0.5).to(_dev())
+    shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
+    ref = ops.stem_conv7x7_bn_relu_maxpool(x.to(_dev()), N, wd, scale, shift)
+    got = ops.stem_u8_conv7x7_bn_relu_maxpool(frames.to(_dev()), wd, scale, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 def test_bad_arguments_raise_not_abort():
     from multiagentperception_amd import ops
     from multiagentperception_amd._native import W2CError
