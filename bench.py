@@ -185,6 +185,23 @@ def main():
                               launch="hip-graph replay" if (model.use_hip_graph and world == 1) else "eager"),
                   roofline=roofline)
 
+    # ---- evaluator fast path, reported beside the headline, never as `value` ---
+    if world == 1:
+        u8 = torch.from_numpy(filler.synthetic_frames_u8(B, n_loc, S, S, 1234 + 2 + rank)).to(dev)
+        for _ in range(args.warmup):
+            model.forward_labels(u8, inference=args.mode)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lab = model.forward_labels(u8, inference=args.mode)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        same = bool(torch.equal(lab[0].long(), out[0].max(1)[1]))
+        result["evaluator_path"] = dict(what="u8 RGB frames -> u8 label maps (loader transform + class argmax fused)",
+                                        value=round(images_per_step * args.steps / el, 2), unit="agent-images/s",
+                                        ms_per_step=round(1e3 * el / args.steps, 4),
+                                        labels_equal_argmax_of_headline_logits=same)
+
     # ---- CPU baseline + parity on a bounded sample (rank 0, single GPU only) ---------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import when2com_oracle as orc

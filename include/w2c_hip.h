@@ -103,6 +103,23 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
                                 void* y, int y_cstride, int y_is_f32,
                                 const void* zero_page, int variant, w2c_stream_t stream);
 
+/* Split-K form of K2 for the tail layers (policy_net4 conv3..5 agent.py:128-132, simple_decoder's last conv
+ * backbone.py:152): few output tiles under a long weight-streaming K loop.  `ksplit` workgroups share a tile, each
+ * summing a contiguous range of K-steps into `workspace` (f32 partial tiles); a second launch adds them in split
+ * order (deterministic) and runs the same epilogue.  ksplit = 0 picks the split (1 = falls through to
+ * w2c_conv_igemm_bf16).  workspace: device memory, 16-B aligned, >= w2c_conv_splitk_workspace_bytes(...) bytes, contents
+ * irrelevant; one workspace may serve consecutive launches on one stream, not concurrent ones. */
+int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                               const uint16_t* w, int Cout, int ksize, int stride, int groups,
+                               const float* scale, const float* shift,
+                               const uint16_t* residual, int relu,
+                               void* y, int y_cstride, int y_is_f32,
+                               const void* zero_page, int ksplit,
+                               void* workspace, long long workspace_bytes, w2c_stream_t stream);
+/* bytes of workspace the call above needs (0: the layer is not split; -1: invalid shape). */
+long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                          int groups, int ksplit);
+
 /* Debug aid (tools/conv_timeline.py): the calling thread's NEXT w2c_conv_igemm_bf16_variant launch records
  * 4 x uint64 wall-clock stamps per workgroup (start, first tile landed, main loop done, end; 100 MHz) into buf
  * (device memory, >= 32 bytes x workgroups). */

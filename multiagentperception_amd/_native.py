@@ -28,6 +28,9 @@ SIGNATURES = {
     "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
     "w2c_conv_igemm_bf16_variant": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
                                     _vp],
+    "w2c_conv_igemm_bf16_splitk": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
+                                   _vp, _c.c_longlong, _vp],
+    "w2c_conv_splitk_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_debug_conv_timeline": [_vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "w2c_head_tail_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp],
@@ -67,7 +70,8 @@ def lib():
             except AttributeError:
                 raise W2CError("libw2c_hip.so does not export %s (stale build?)" % name)
             fn.argtypes = argtypes
-            fn.restype = _c.c_char_p if name in ("w2c_status_string", "w2c_last_error_string") else _i
+            fn.restype = (_c.c_char_p if name in ("w2c_status_string", "w2c_last_error_string") else
+                          _c.c_longlong if name == "w2c_conv_splitk_workspace_bytes" else _i)
         _lib = handle
     return _lib
 

@@ -49,6 +49,8 @@ struct ConvArgs {
     int ktiles;      // ks*ks*cin_tiles
     int ntm, ntn;    // tiles along rows / cout
     unsigned long long* dbg;   // optional timeline buffer (tools/conv_timeline.py): 4 x u64 per workgroup, else null
+    float* ws;                 // split-K: f32 partial tiles [group][tile][split][BM][BN]
+    int n_split;
 };
 
 __device__ __forceinline__ void dbg_stamp(const ConvArgs& p, int slot) {
@@ -71,7 +73,11 @@ __device__ __forceinline__ void pipeline_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int STAGES>
+// SPLITK: gridDim.z workgroups share one output tile, each accumulating a contiguous range of the K-steps; partial
+// tiles go to p.ws as f32 and splitk_finish_kernel sums them in split order (fixed order: deterministic) and runs
+// the epilogue.  For the tail layers (<= 80 tiles under a long, weight-streaming K loop) this turns a 36-step
+// latency chain into 4-5 steps on 8x the CUs.
+template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool SPLITK = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -145,8 +151,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         b_off[j] = (unsigned)(((size_t)(n0 + n) * Ktot + (lpos ^ swz(n)) * 8) * 2);
     }
 
-    // K-step cursor (wave-uniform): tap (ky,kx) and channel chunk
-    int st_ky = 0, st_kx = 0, st_ct = 0, st_kt = 0;
+    // K-step range of this workgroup and cursor (wave-uniform): tap (ky,kx) and channel chunk
+    const int n_split = SPLITK ? (int)gridDim.z : 1;
+    const int z = SPLITK ? (int)blockIdx.z : 0;
+    const int t_begin = SPLITK ? (z * p.ktiles) / n_split : 0;
+    const int t_end = SPLITK ? ((z + 1) * p.ktiles) / n_split : p.ktiles;
+    int st_kt = t_begin, st_ct = t_begin % p.cin_tiles;
+    int st_ky = (t_begin / p.cin_tiles) / p.ks, st_kx = (t_begin / p.cin_tiles) % p.ks;
 
     auto stage = [&](int buf) {
         char* As = smem + buf * STAGE_BYTES;
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     };
 
     // ---- main loop: STAGES-deep ring, counted waits, one barrier per K-step ----
-    const int KT = p.ktiles;
+    const int KT = t_end - t_begin;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < KT) stage(s);
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         e_ok[ps] = gr < p.rows;
         e_off[ps] = (size_t)(e_ok[ps] ? gr : 0) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
     }
-    if (p.res) {
+    if (p.res && !SPLITK) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) e_res[ps] = *reinterpret_cast<const uint4*>(p.res + e_off[ps]);
     } else {
@@ -263,17 +274,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int nl = wn * WTN + j * 32 + l31;
-        const float sc = e_sc[j], sh = e_sh[j];
+        const float sc = SPLITK ? 1.f : e_sc[j], sh = SPLITK ? 0.f : e_sh[j];   // split-K: raw partial sums
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;   // C/D row map of 32x32 MFMA
-                Cs[ml * CLD + nl] = acc[i][j][e] * sc + sh;
+                Cs[ml * CLD + nl] = SPLITK ? acc[i][j][e] : acc[i][j][e] * sc + sh;
             }
         }
     }
     __syncthreads();
+
+    if constexpr (SPLITK) {
+        // partial tile -> workspace (coalesced 32-B pieces); splitk_finish_kernel (next launch on the stream) sums the
+        // partial tiles in split order and runs the epilogue.  (An in-kernel "last arriver reduces" hand-off needs a
+        // device-scope release/acquire per workgroup = an L2 write-back on this 8-XCD part: measured 27 -> 120 us.)
+        const size_t tile_id = (size_t)g * (p.ntm * p.ntn) + tile;
+        float* slab = p.ws + (tile_id * n_split + z) * (size_t)(BM * BN);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int idx = ps * NT + tid;
+            const int r = idx / CG, cg = idx - r * CG;
+            *reinterpret_cast<f32x4_t*>(slab + r * BN + cg * 8) = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8);
+            *reinterpret_cast<f32x4_t*>(slab + r * BN + cg * 8 + 4) = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4);
+        }
+        return;
+    }
 
     // ---- epilogue 2: coalesced (+residual) (+ReLU) store, 8 channels per thread per pass ----
 #pragma unroll
@@ -639,6 +666,99 @@ constexpr int conv_lds_bytes() {
     return ring > epi ? ring : epi;
 }
 
+// Second half of a split-K conv: out = act(scale * sum_z partial_z + shift (+ residual)); one thread per 8 channels.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
+    constexpr int CG = BN / 8;
+    const int g = blockIdx.y;
+    const long total = (long)p.ntm * p.ntn * BM * CG;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int cg = (int)(id % CG);
+    const long t1 = id / CG;
+    const int r = (int)(t1 % BM);
+    const int tile = (int)(t1 / BM);                         // == xcd_remap'ed tile id used by the producer
+    const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+    const int gr = tm * BM + r;
+    if (gr >= p.rows) return;
+    const float* sp = p.ws + (((size_t)g * (p.ntm * p.ntn) + tile) * p.n_split) * (size_t)(BM * BN) + r * BN + cg * 8;
+    f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    for (int z = 0; z < p.n_split; ++z) {
+        v0 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN));
+        v1 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN) + 4);
+    }
+    const int ch = g * p.Cout + tn * BN + cg * 8;
+    v0 = v0 * *reinterpret_cast<const f32x4_t*>(p.scale + ch) + *reinterpret_cast<const f32x4_t*>(p.shift + ch);
+    v1 = v1 * *reinterpret_cast<const f32x4_t*>(p.scale + ch + 4) + *reinterpret_cast<const f32x4_t*>(p.shift + ch + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const size_t off = (size_t)gr * p.ycs + ch;
+    if (p.res) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(p.res + off);
+        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += bf16_to_f32((uint16_t)(rw[e] & 0xFFFFu));
+            v[2 * e + 1] += bf16_to_f32((uint16_t)(rw[e] >> 16));
+        }
+    }
+    if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (p.y_f32) {
+        float* yo = reinterpret_cast<float*>(p.y) + off;
+        *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+    } else {
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + off) = o;
+    }
+}
+
+// split-K launch of the generic kernel (grid.z = ksplit) + its finish kernel
+template <int BM, int BN, int WM, int WN>
+int launch_conv_splitk(ConvArgs& a, int groups, int ksplit, hipStream_t s) {
+    constexpr int BK = 64, STAGES = 2;
+    if (a.Cin % BK != 0 || a.Cout % BN != 0) return W2C_E_ARG;
+    a.cin_tiles = a.Cin / BK;
+    a.ktiles = a.ks * a.ks * a.cin_tiles;
+    a.ntm = (a.rows + BM - 1) / BM;
+    a.ntn = a.Cout / BN;
+    if (ksplit < 1 || ksplit > a.ktiles) return W2C_E_ARG;
+    constexpr int lds = conv_lds_bytes<BM, BN, BK, STAGES>();
+    static_assert(lds <= 64 * 1024, "LDS");
+    a.n_split = ksplit;
+    dim3 grid(a.ntm * a.ntn, groups, ksplit);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, true>), grid, dim3(64 * WM * WN), lds, s, a);
+    const int rc = w2c_launch_status();
+    if (rc != W2C_OK) return rc;
+    const long threads = (long)a.ntm * a.ntn * BM * (BN / 8);
+    hipLaunchKernelGGL((splitk_finish_kernel<BM, BN>), dim3((unsigned)((threads + 255) / 256), groups), dim3(256), 0, s, a);
+    return w2c_launch_status();
+}
+
+// tile shape + split count for a split-K launch; ksplit == 1 means "not worth splitting"
+struct SplitPlan { int bm, bn, tiles, ksplit; };
+SplitPlan plan_splitk(const ConvArgs& a, int groups, int want) {
+    SplitPlan sp;
+    sp.bn = (a.Cout % 64 == 0) ? 64 : 32;
+    sp.bm = sp.bn == 64 ? 64 : 128;
+    sp.tiles = (int)(((long)a.rows + sp.bm - 1) / sp.bm) * (a.Cout / sp.bn) * groups;
+    const int kt = a.ks * a.ks * (a.Cin / 64);
+    int ks = want;
+    if (ks <= 0) {                                         // auto: ~2 workgroups per CU, >= 3 K-steps each
+        ks = (512 + sp.tiles - 1) / sp.tiles;
+        if (ks > kt / 3) ks = kt / 3;
+        if (sp.tiles >= 256) ks = 1;
+    }
+    if (ks < 1) ks = 1;
+    if (ks > kt) ks = kt;
+    sp.ksplit = ks;
+    return sp;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int STAGES>
 int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
     if (a.Cin % BK != 0 || a.Cout % BN != 0) return W2C_E_ARG;
@@ -749,6 +869,8 @@ int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int 
     a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;
     a.rows = M * a.Ho * a.Wo;
     a.dbg = nullptr;
+    a.ws = nullptr;
+    a.n_split = 1;
     return W2C_OK;
 }
 
@@ -767,6 +889,41 @@ extern "C" int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int C
     if (rc != W2C_OK) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return launch_variant(pick_variant(a, groups), a, groups, s);
+}
+
+extern "C" long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                                     int groups, int ksplit) {
+    if (M <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % 32 || groups <= 0) return -1;
+    if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return -1;
+    ConvArgs a;
+    a.ks = ksize; a.Cin = Cin; a.Cout = Cout;
+    const int pad = ksize == 3 ? 1 : 0;
+    a.rows = M * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+    const SplitPlan sp = plan_splitk(a, groups, ksplit);
+    if (sp.ksplit <= 1) return 0;
+    return (long long)sp.tiles * sp.ksplit * sp.bm * sp.bn * 4;
+}
+
+extern "C" int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                          const uint16_t* w, int Cout, int ksize, int stride, int groups,
+                                          const float* scale, const float* shift,
+                                          const uint16_t* residual, int relu,
+                                          void* y, int y_cstride, int y_is_f32,
+                                          const void* zero_page, int ksplit,
+                                          void* workspace, long long workspace_bytes, w2c_stream_t stream) {
+    w2c_clear_error();
+    ConvArgs a;
+    int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
+                       y, y_cstride, y_is_f32, zero_page);
+    if (rc != W2C_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const SplitPlan sp = plan_splitk(a, groups, ksplit);
+    if (sp.ksplit <= 1) return launch_variant(pick_variant(a, groups), a, groups, s);
+    const long long need = (long long)sp.tiles * sp.ksplit * sp.bm * sp.bn * 4;
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return W2C_E_ARG;
+    a.ws = reinterpret_cast<float*>(workspace);
+    return sp.bn == 64 ? launch_conv_splitk<64, 64, 2, 2>(a, groups, sp.ksplit, s)
+                       : launch_conv_splitk<128, 32, 4, 1>(a, groups, sp.ksplit, s);
 }
 
 // Debug: next w2c_conv_igemm_bf16_variant call of THIS thread writes a workgroup timeline (4 x u64

@@ -17,6 +17,8 @@ of that tensor and the policy net continues from channels [512,1024).
 Eval-mode BatchNorm and conv biases are folded into an f32 per-channel (scale, shift) applied
 to the f32 accumulator (weights are rounded to bf16 unscaled).
 """
+import os
+
 import torch
 
 from . import ops
@@ -73,8 +75,10 @@ class ConvPlan:
         self.shift = torch.cat(shs).contiguous()
 
     def run(self, x, x_ch_off=0, residual=None, out_f32=False):
+        # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
-                              self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32)
+                              self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,
+                              ksplit=None if os.environ.get('W2C_NO_SPLITK') else 0)
 
 
 class TrunkPlan:

@@ -140,10 +140,25 @@ def maxpool3x3s2(x, out=None):
     return out
 
 
+_splitk_ws = {}
+
+
+def splitk_workspace(dev, nbytes):
+    """Per-device split-K scratch (zeroed once; the kernel restores its counters to zero).  Launches that share it
+    are ordered by the stream they run on."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(int(nbytes), 16 << 20), dtype=torch.uint8, device=dev)
+        _splitk_ws[key] = ws
+    return ws
+
+
 def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
-               out=None, out_f32=False, out_cstride=None, variant=None):
+               out=None, out_f32=False, out_cstride=None, variant=None, ksplit=None):
     """x: bf16 NHWC [M,H,W,xcs]; the conv reads channels [x_ch_off + g*cin, ...).  Returns/accepts
-    out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32)."""
+    out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32).  ksplit: None = one workgroup per tile;
+    0 = split-K chosen by the library for tail layers; n = forced n-way split."""
     dev = _need_gpu(x, w_packed, scale, shift, residual, out)
     M, H, W, xcs = x.shape
     pad = 1 if ksize == 3 else 0
@@ -164,7 +179,19 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
     with torch.cuda.device(dev):
-        if variant is None:
+        ws_bytes = 0
+        if ksplit is not None and variant is None:
+            ws_bytes = _native.lib().w2c_conv_splitk_workspace_bytes(M, H, W, cin, cout, ksize, stride, groups, int(ksplit))
+            if ws_bytes < 0:
+                raise W2CError("conv split-K: unsupported shape")
+        if ws_bytes > 0:
+            ws = splitk_workspace(dev, ws_bytes)
+            check(_native.lib().w2c_conv_igemm_bf16_splitk(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride,
+                                                           groups, _p(scale), _p(shift), _p(residual),
+                                                           1 if relu else 0, _p(out), out_cstride,
+                                                           1 if out_f32 else 0, _p(zero_page(dev)), int(ksplit),
+                                                           _p(ws), ws.numel(), _stream(dev)), "w2c_conv_igemm_bf16_splitk")
+        elif variant is None:
             check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
                                                     _p(scale), _p(shift), _p(residual), 1 if relu else 0,
                                                     _p(out), out_cstride, 1 if out_f32 else 0,

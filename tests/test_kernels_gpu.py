@@ -160,6 +160,58 @@ def test_conv_variants_match_fp32_conv(case):
         np.testing.assert_allclose(_to_nchw(y, g * cout, cout).numpy(), ref.numpy(), atol=2e-4, rtol=2e-4)
 
 
+SPLITK_CASES = [
+    # ksplit, M, H, W, Cin, Cout, ks, stride, groups, residual, f32out
+    (0, 20, 16, 16, 256, 256, 3, 2, 1, False, False),      # policy conv3 (auto split)
+    (0, 20, 4, 4, 256, 256, 3, 2, 1, False, False),        # policy conv5: 80 output rows, partial tiles
+    (0, 20, 16, 16, 256, 32, 3, 1, 1, False, True),        # decoder's last conv (Cout padded to 32, f32 logits)
+    (3, 3, 9, 7, 128, 64, 3, 1, 2, True, False),           # forced 3-way, ragged rows, both groups, residual
+    (18, 1, 8, 8, 128, 64, 3, 1, 1, True, True),           # one K-step per workgroup
+    (4, 2, 8, 8, 256, 128, 1, 1, 1, False, False),         # 1x1
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=["k%d-%d" % (c[0], i) for i, c in enumerate(SPLITK_CASES)])
+def test_conv_splitk_matches_fp32_and_is_deterministic(case):
+    """Split-K tail-layer path: fp32 parity, bit-identical across repeated launches (fixed summation order, arrival
+    counters restored), and equal to the one-workgroup-per-tile kernel up to f32 summation order."""
+    from multiagentperception_amd import ops
+    ksplit, M, H, W, cin, cout, ks, stride, G, use_res, f32out = case
+    gen = torch.Generator().manual_seed(7000 + ksplit + cout)
+    pad = 1 if ks == 3 else 0
+    xs = [_rand(gen, M, cin, H, W) for _ in range(G)]
+    ws = [_rand(gen, cout, cin, ks, ks, scale=(2.0 / (cin * ks * ks)) ** 0.5) for _ in range(G)]
+    scale = torch.rand(G * cout, generator=gen) + 0.5
+    shift = torch.randn(G * cout, generator=gen) * 0.1
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    ress = [_rand(gen, M, cout, Ho, Wo) for _ in range(G)] if use_res else None
+    x_dev = torch.cat([x.permute(0, 2, 3, 1) for x in xs], 3).to(BF16).contiguous().to(_dev())
+    w_dev = torch.stack([w.permute(0, 2, 3, 1).reshape(cout, -1).to(BF16) for w in ws], 0).contiguous().to(_dev())
+    res_dev = torch.cat([r.permute(0, 2, 3, 1) for r in ress], 3).to(BF16).contiguous().to(_dev()) if use_res else None
+    kw = dict(residual=res_dev, relu=True, out_f32=f32out)
+    args = (x_dev, 0, cin, w_dev, cout, ks, stride, G, scale.to(_dev()), shift.to(_dev()))
+    first = ops.conv_igemm(*args, ksplit=ksplit, **kw).clone()
+    for _ in range(10):
+        again = ops.conv_igemm(*args, ksplit=ksplit, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(again, first)
+    plain = ops.conv_igemm(*args, **kw)
+    torch.cuda.synchronize()
+    assert float((first.float() - plain.float()).abs().max()) <= (1e-4 if f32out else 0.0626)
+    for g in range(G):
+        ref = F.conv2d(xs[g], ws[g], None, stride=stride, padding=pad)
+        ref = ref * scale[g * cout:(g + 1) * cout].view(1, -1, 1, 1) + shift[g * cout:(g + 1) * cout].view(1, -1, 1, 1)
+        if use_res:
+            ref = ref + ress[g]
+        ref = F.relu(ref)
+        got = _to_nchw(first, g * cout, cout)
+        if f32out:
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-4, rtol=2e-4)
+        else:
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
+
+
 @pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (31, 64, 64, 128), (36, 64, 64, 128), (38, 64, 64, 128),
                                                  (33, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16)])
 def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
