@@ -635,6 +635,337 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #endif
 }
 
+
+// =====================================================================================================
+// Layer1 kernel: 3x3 stride-1, Cin = Cout = 64 per group, weights stationary in REGISTERS.
+//
+// K = 576 is only 9 K-steps of the ring kernels above: a 128-pixel tile is ~1 us of MFMA work per wave under
+// 9 barriers, a cold prologue and a 3 us epilogue -- layer1 ran at 25 % of the MFMA peak and 2x its HBM time.
+// Here the whole 64 x 576 weight matrix of the group (73 KB) lives in the wave's registers for the kernel's
+// lifetime (72 MFMA A-fragments = 288 of the 512 VGPR+AGPR of a 1-wave-per-SIMD kernel; MFMA A/B operands may be
+// AGPRs on gfx950), and each WAVE is an independent persistent worker:
+//   * it owns a contiguous run of 4 x 16-pixel tiles (XCD-contiguous, so the halo rows of neighbouring waves meet
+//     in one L2) and two private 6 x 18-pixel patch buffers in LDS;
+//   * the patch of tile t+1 and the residual tile of tile t arrive by LDS-DMA (buffer_load ... lds; out-of-image
+//     halo pixels are out-of-range offsets -> zeros) while tile t's 144 MFMAs run; B fragments (pixels) are one
+//     ds_read_b128 each, 0.5 per MFMA;
+//   * NO workgroup barrier anywhere: every LDS byte a wave reads was written by that wave (DMA + s_waitcnt vmcnt,
+//     or its own in-order ds_writes);
+//   * epilogue: the dead patch buffer becomes the f32 staging of 32 pixels x 64 channels (row pitch 272 B:
+//     conflict-free ds_write_b128), read back as 8-channel groups, + scale/shift + residual (from LDS) + ReLU,
+//     16-byte coalesced bf16 stores.
+// vmcnt bookkeeping per tile: [patch(t+1) x14, residual(t) x8] are issued at the top of tile t and waited for
+// (vmcnt(0)) before epilogue(t), ~4.6k MFMA cycles later; that wait also retires the stores of tile t-1.
+template <bool HAS_RES>
+__global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PW = 18;                         // patch width (16 + 2 halo); 6 rows
+    constexpr int PATCH_BYTES = 14 * 1024;         // 14 DMA instructions x 8 pixels x 128 B (108 pixels used)
+    constexpr int RES_BYTES = 8 * 1024;            // 64 pixels x 128 B
+    constexpr int WAVE_LDS = 2 * PATCH_BYTES + RES_BYTES;
+    constexpr int SPITCH = 272;                    // staging row pitch, bytes
+    constexpr int WPITCH = 1152 + 16;              // prologue weight rows in LDS: 16-B pad => conflict-free fragment reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int g = blockIdx.y;
+    char* const wl = smem + wave * WAVE_LDS;
+    char* const resbuf = wl + 2 * PATCH_BYTES;
+
+    // ---- weights -> registers: A operand, row = output channel, k = (tap, cin).  The register CLASS is pinned by the
+    // inline-asm MFMAs below: channel tile 0 (144 regs) + the 64 accumulators live in AGPRs, channel tile 1 in VGPRs.
+    // Left to the compiler, all 288 land in VGPR-class values that are spilled to / re-read from AGPRs around every use
+    // and the B-fragment reads lose their double buffer (measured 102 us vs 72 us for the ring kernel).
+    // A fragment is 16 B out of a 1152-B weight row: gathering it straight from global memory costs 72 uncoalesced
+    // loads per lane, so the group's 73 KB go through LDS once (coalesced in, fragment-shaped out). ----
+    const unsigned long long wall0 = p.dbg ? wall_clock64() : 0;
+    u32x4_t wa[9][4], wv[9][4];
+    {
+        const uint16_t* wg = p.w + (size_t)g * 64 * 576;
+        for (int c = tid; c < 64 * 72; c += 256) {
+            const int row = c / 72, col = c - row * 72;
+            *reinterpret_cast<uint4*>(smem + row * WPITCH + col * 16) = *reinterpret_cast<const uint4*>(wg + row * 576 + col * 8);
+        }
+        if (tid < 64) {                            // BN scale | shift of the group: 512 B after the waves' regions
+            reinterpret_cast<float*>(smem + 4 * WAVE_LDS)[tid] = p.scale[g * 64 + tid];
+            reinterpret_cast<float*>(smem + 4 * WAVE_LDS)[64 + tid] = p.shift[g * 64 + tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                wa[tap][kc] = *reinterpret_cast<const u32x4_t*>(smem + l31 * WPITCH + tap * 128 + kc * 32 + lhi * 16);
+                wv[tap][kc] = *reinterpret_cast<const u32x4_t*>(smem + (32 + l31) * WPITCH + tap * 128 + kc * 32 + lhi * 16);
+            }
+        __syncthreads();                           // the only workgroup barriers of the kernel: LDS is reused below
+    }
+
+    // ---- tiles of this wave: a contiguous run, XCD-contiguous across the grid ----
+    const int ntx = p.W >> 4, nty = p.H >> 2, tpi = ntx * nty;
+    const int T = p.M * tpi;
+    const int nwg = gridDim.x;
+    const int b = blockIdx.x;
+    const int logical = (nwg % 8 == 0) ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
+    const int wid = logical * 4 + wave, nw = nwg * 4;
+    const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long)wid * T) / nw));      // wave-uniform, and the
+    const int t_end = __builtin_amdgcn_readfirstlane((int)(((long)(wid + 1) * T) / nw));    // compiler should know it
+    if (t_begin >= t_end) return;
+
+    // ---- DMA constants.  Patch instruction j moves pixels q = 8j + lane/8 (q = row*18 + col), lane%8 = LDS chunk
+    // position; the bank swizzle (chunk c of pixel q sits at c ^ ((q>>1)&7)) is applied to the SOURCE chunk. ----
+    const size_t x_bytes = (size_t)p.M * p.H * p.W * p.xcs * 2;
+    const size_t y_bytes = (size_t)p.M * p.H * p.W * p.ycs * (p.y_f32 ? 4 : 2);
+    const size_t r_bytes = (size_t)p.M * p.H * p.W * p.ycs * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.x + (size_t)g * 64), 0, (int)(x_bytes - (size_t)g * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>((HAS_RES ? p.res : p.x) + (size_t)g * 64), 0, (int)((HAS_RES ? r_bytes : x_bytes) - (size_t)g * 128),
+        0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)y_bytes, 0x00020000);
+    int off_rel[14];
+    unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_inval = 0;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const int q = 8 * j + (lane >> 3);
+        const int dy = (q * 3641) >> 16, dx = q - dy * PW;          // q / 18, q % 18 for q < 128
+        const int chunk = (lane & 7) ^ ((q >> 1) & 7);
+        off_rel[j] = ((dy * p.W + dx) * p.xcs + chunk * 8) * 2;
+        m_top |= (dy == 0 ? 1u : 0u) << j;
+        m_bot |= (dy == 5 ? 1u : 0u) << j;
+        m_left |= (dx == 0 ? 1u : 0u) << j;
+        m_right |= (dx == 17 ? 1u : 0u) << j;
+        m_inval |= (q >= 6 * PW ? 1u : 0u) << j;
+    }
+    const unsigned r_lane = (unsigned)(((lane >> 3) * p.ycs + (lane & 7) * 8) * 2);        // residual DMA: pixel lane/8, chunk lane%8
+    const int cg = lane & 7;                                                               // read-out: 8-channel group
+    const unsigned y_lane = (unsigned)(((lane >> 3) * p.ycs + g * 64 + cg * 8) * (p.y_f32 ? 4 : 2));
+
+    auto tile_coords = [&](int t, int& img, int& y0, int& x0) {
+        img = t / tpi;
+        const int r = t - img * tpi;
+        const int ty = r / ntx;
+        y0 = ty * 4;
+        x0 = (r - ty * ntx) * 16;
+    };
+    // patch DMA of one tile = 14 instructions; `pbase` / `pbad` are its wave-uniform base offset and halo mask
+    int pbase = 0;
+    unsigned pbad = 0;
+    auto patch_setup = [&](int t, bool live) {
+        int img, y0, x0;
+        tile_coords(t, img, y0, x0);
+        pbase = (((img * p.H + y0 - 1) * p.W) + x0 - 1) * p.xcs * 2;          // bytes; negative only where the halo lanes are off
+        pbad = !live ? 0xFFFFFFFFu
+                     : (m_inval | (y0 == 0 ? m_top : 0u) | (y0 + 4 == p.H ? m_bot : 0u) | (x0 == 0 ? m_left : 0u) |
+                        (x0 + 16 == p.W ? m_right : 0u));
+    };
+    auto patch_piece = [&](int j, char* dst) {
+        const unsigned vo = ((pbad >> j) & 1u) ? 0x80000000u : (unsigned)(pbase + off_rel[j]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(dst + j * 1024), 16, vo, 0, 0, 0);
+    };
+    int rbase = 0;
+    auto residual_piece = [&](int j) {       // instruction j: pixels 8j..8j+7 of the 4 x 16 tile (row j/2, cols 8(j&1)..)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, W2C_LPTR(resbuf + j * 1024), 16, r_lane,
+                                                 rbase + ((j >> 1) * p.W + 8 * (j & 1)) * p.ycs * 2, 0, 0);
+    };
+
+    // B-fragment geometry: MFMA pixel tile pt = rows 2pt, 2pt+1 of the 4 x 16 tile; lane's pixel = (l31>>4, l31&15)
+    int qb[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) qb[pt] = (pt * 2 + (l31 >> 4)) * PW + (l31 & 15);
+    const char* const ssb = smem + 4 * WAVE_LDS + cg * 32;     // this lane's 8 channels' scale (+256: shift), re-read per tile
+
+    int cur = 0;
+    patch_setup(t_begin, true);
+#pragma unroll
+    for (int j = 0; j < 14; ++j) patch_piece(j, wl);
+    unsigned long long ph[4] = {0, 0, 0, 0};       // debug (p.dbg): cycles at tile top | MFMA loop | vmcnt wait | epilogue
+    const unsigned long long wall1 = p.dbg ? wall_clock64() : 0;
+    long long tp = p.dbg ? clock64() : 0;
+    auto stamp = [&](int i) {
+        if (p.dbg) { const long long n = clock64(); ph[i] += (unsigned long long)(n - tp); tp = n; }
+    };
+    int img, y0, x0;
+    tile_coords(t_begin, img, y0, x0);
+    for (int t = t_begin; t < t_end; ++t) {
+        char* const pc = wl + cur * PATCH_BYTES;
+        char* const pn = wl + (cur ^ 1) * PATCH_BYTES;
+        // tile t -> (img, y0, x0) incrementally (the divisions of tile_coords cost ~500 cycles per tile on one wave)
+        if (t != t_begin) {
+            x0 += 16;
+            if (x0 == p.W) { x0 = 0; y0 += 4; if (y0 == p.H) { y0 = 0; ++img; } }
+        }
+        rbase = ((img * p.H + y0) * p.W + x0) * p.ycs * 2;
+        {   // patch(t+1): base offset + halo mask; on the last tile every lane is off (zeros into the idle buffer)
+            int xn = x0 + 16, yn = y0, in = img;
+            if (xn == p.W) { xn = 0; yn += 4; if (yn == p.H) { yn = 0; ++in; } }
+            const bool live = t + 1 < t_end;
+            pbase = (((in * p.H + yn - 1) * p.W) + xn - 1) * p.xcs * 2;
+            pbad = !live ? 0xFFFFFFFFu
+                         : (m_inval | (yn == 0 ? m_top : 0u) | (yn + 4 == p.H ? m_bot : 0u) | (xn == 0 ? m_left : 0u) |
+                            (xn + 16 == p.W ? m_right : 0u));
+        }
+        if (t == t_begin) wait_vmcnt<0>();         // later tiles: patch(t) was waited for before epilogue(t-1)
+        asm volatile("" ::: "memory");
+        stamp(0);
+
+        // 36 K-steps (tap, 16-channel chunk), fully unrolled; the B fragments of step s+1 are read before the MFMAs of
+        // step s are issued, and the 8 + 14 LDS-DMA instructions of residual(t) / patch(t+1) are spread one per K-step
+        // through the MFMA stream (issued back to back at the tile top they cost ~95 cycles each with the MFMA pipe idle).
+        f32x16_t acc[2][2];
+        // fragment address of (tap, kc) for pixel q = qb + ky*18 + kx:  q*128 + ((2kc | lhi) ^ ((q>>1)&7))*16
+        //                                                             = fb + ((kc << 5) ^ fx),  fb, fx per (tap, pt).
+        // qv is laundered through an empty asm once per tile so the 72 addresses are NOT hoisted out of the tile loop
+        // (they would cost 72 registers; recomputed they are ~2 VALU per read in the MFMA shadow).
+        int qv0 = qb[0], qv1 = qb[1];
+        asm volatile("" : "+v"(qv0), "+v"(qv1));
+        int fb[2], fx[2];
+        auto tap_setup = [&](int tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int q0 = qv0 + ky * PW + kx, q1 = qv1 + ky * PW + kx;
+            fb[0] = q0 * 128; fx[0] = ((lhi ^ (q0 >> 1)) & 7) << 4;
+            fb[1] = q1 * 128; fx[1] = ((lhi ^ (q1 >> 1)) & 7) << 4;
+        };
+        auto frag = [&](int kc, int pt) { return *reinterpret_cast<const u32x4_t*>(pc + fb[pt] + ((kc << 5) ^ fx[pt])); };
+        u32x4_t bx[2][2];
+        tap_setup(0);
+        bx[0][0] = frag(0, 0);
+        bx[0][1] = frag(0, 1);
+#pragma unroll
+        for (int step = 0; step < 36; ++step) {
+            const int tap = step >> 2, kc = step & 3, cb = step & 1;
+            if (step + 1 < 36) {
+                if (((step + 1) & 3) == 0) tap_setup((step + 1) >> 2);
+                bx[cb ^ 1][0] = frag((step + 1) & 3, 0);
+                bx[cb ^ 1][1] = frag((step + 1) & 3, 1);
+            }
+            if (HAS_RES && step >= 1 && step <= 8) residual_piece(step - 1);
+            if (step >= 9 && step <= 22) patch_piece(step - 9, pn);
+            if (step == 0) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[0][0]) : "a"(wa[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[0][1]) : "v"(wv[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[1][0]) : "a"(wa[tap][kc]), "v"(bx[cb][1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[1][1]) : "v"(wv[tap][kc]), "v"(bx[cb][1]));
+            } else {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0][0]) : "a"(wa[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0][1]) : "v"(wv[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[1][0]) : "a"(wa[tap][kc]), "v"(bx[cb][1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[1][1]) : "v"(wv[tap][kc]), "v"(bx[cb][1]));
+            }
+        }
+        // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> VALU/DS-read wait states by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        stamp(1);
+
+        // ---- epilogue ----
+        char* const stage = pc;                    // the patch of tile t is dead: f32 staging, 32 pixels x 64 channels
+        const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssb), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssb + 16);
+        const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(ssb + 256), e_sh1 = *reinterpret_cast<const f32x4_t*>(ssb + 272);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            // D layout: lane = pixel l31, acc element e = channel (e&3) + 8(e>>2) + 4 lhi of the 32-channel tile ct
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg)
+                    *reinterpret_cast<f32x4_t*>(stage + l31 * SPITCH + (ct * 32 + eg * 8 + lhi * 4) * 4) =
+                        f32x4_t{acc[pt][ct][eg * 4], acc[pt][ct][eg * 4 + 1], acc[pt][ct][eg * 4 + 2], acc[pt][ct][eg * 4 + 3]};
+            if (pt == 0) {     // residual(t) and patch(t+1) were issued 14+ K-steps ago; this also retires the stores of tile t-1
+                asm volatile("" ::: "memory");
+                wait_vmcnt<0>();
+                asm volatile("" ::: "memory");
+                stamp(2);
+            }
+            f32x4_t v0[4], v1[4];
+            uint4 rr[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {       // read-out item: pixel it*8 + lane/8 of the MFMA tile, channels cg*8..+8
+                const char* sp = stage + (it * 8 + (lane >> 3)) * SPITCH + cg * 32;
+                v0[it] = *reinterpret_cast<const f32x4_t*>(sp);
+                v1[it] = *reinterpret_cast<const f32x4_t*>(sp + 16);
+                if constexpr (HAS_RES)             // tile pixel = (pt*2 + it/2, (it&1)*8 + lane/8)
+                    rr[it] = *reinterpret_cast<const uint4*>(resbuf + ((pt * 2 + (it >> 1)) * 16 + (it & 1) * 8 + (lane >> 3)) * 128 + cg * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                f32x4_t a0 = v0[it] * e_sc0 + e_sh0;
+                f32x4_t a1 = v1[it] * e_sc1 + e_sh1;
+                if constexpr (HAS_RES) {
+                    const uint32_t rw[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    a0 += f32x4_t{__uint_as_float(rw[0] << 16), __uint_as_float(rw[0] & 0xFFFF0000u),
+                                  __uint_as_float(rw[1] << 16), __uint_as_float(rw[1] & 0xFFFF0000u)};
+                    a1 += f32x4_t{__uint_as_float(rw[2] << 16), __uint_as_float(rw[2] & 0xFFFF0000u),
+                                  __uint_as_float(rw[3] << 16), __uint_as_float(rw[3] & 0xFFFF0000u)};
+                }
+                const int pix = ((pt * 2 + (it >> 1)) * p.W + (it & 1) * 8);                     // tile-relative pixel, uniform
+                const int tile_pix = (img * p.H + y0) * p.W + x0;
+                if (p.y_f32) {
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a0[e] = fmaxf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f); }
+                    }
+                    const int so = (tile_pix + pix) * p.ycs * 4;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a0), rs_y, y_lane, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a1), rs_y, y_lane + 16, so, 0);
+                } else {
+                    // ReLU after the bf16 rounding, on the packed pairs: rounding keeps the sign, and a signed 16-bit
+                    // max with 0 clears exactly the negative bf16 (incl. -0) -- same bits as fmaxf before the rounding
+                    uint32_t ow[4] = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]),
+                                      pack_bf16x2(a1[2], a1[3])};
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const s16x2_t h = __builtin_bit_cast(s16x2_t, ow[e]);
+                            ow[e] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(h, s16x2_t{0, 0}));
+                        }
+                    }
+                    const u32x4_t o = {ow[0], ow[1], ow[2], ow[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, y_lane, (tile_pix + pix) * p.ycs * 2, 0);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        stamp(3);
+        cur ^= 1;
+    }
+    if (p.dbg && lane == 0 && wave == 0) {         // 8 x u64 per workgroup: 4 phase sums (shader cycles), 3 wall stamps (100 MHz)
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = ph[i];
+        d[4] = wall0; d[5] = wall1; d[6] = wall_clock64(); d[7] = 1;
+    }
+#endif
+}
+
+template <bool HAS_RES>
+int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
+    constexpr int lds = 4 * (2 * 14 * 1024 + 8 * 1024) + 512;    // 4 waves' patch/residual buffers + scale/shift
+    static unsigned long long attr_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int n_cu[64] = {0};
+    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_regw_kernel<HAS_RES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipDeviceProp_t prop;
+        n_cu[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                             ? prop.multiProcessorCount : 256;
+        attr_mask |= 1ull << (dev & 63);
+    }
+    const long tiles = (long)a.M * (a.H / 4) * (a.W / 16);
+    int wgs = (n_cu[dev & 63] + groups - 1) / groups;            // one 4-wave workgroup per CU, split over the groups
+    wgs = (wgs + 7) / 8 * 8;
+    if ((long)wgs * 4 > tiles) wgs = (int)((tiles + 3) / 4);
+    hipLaunchKernelGGL((conv3x3_c64_regw_kernel<HAS_RES>), dim3(wgs, groups), dim3(256), lds, s, a);
+    return w2c_launch_status();
+}
+
+int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
+    if (a.ks != 3 || a.stride != 1 || a.Cin != 64 || a.Cout != 64 || a.H % 4 != 0 || a.W % 16 != 0) return W2C_E_ARG;
+    if ((size_t)a.M * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.M * a.H * a.W * a.ycs * 2 >= (1ull << 31)) return W2C_E_ARG;
+    return a.res ? launch_regw<true>(a, groups, s) : launch_regw<false>(a, groups, s);
+}
+
 template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
@@ -823,6 +1154,8 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         // Cin == 64 (one channel chunk): a single patch buffer -> ~39 KB of LDS -> four workgroups per CU
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
         case 39: return launch_patch<8, 16, 64, 4, 2, 2, 1>(a, groups, s);
+        // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
+        case 50: return launch_regw_any(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -830,7 +1163,8 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
 // Per-layer kernel choice, from the per-layer sweeps of tools/bench_conv.py on MI355X
 // (profiles/r01_b_conv_variant_sweep.txt; run-to-run noise of single cells is ~+-8 %).  Stride-1 3x3 convs go to
 // the patch-staged kernel with 128-pixel (8x16) tiles sized so that >= 2 workgroups share a CU:
-//   Cin == 64  (layer1: one channel chunk) -> v38: single patch buffer, 39 KB LDS, four workgroups per CU
+//   Cin == Cout == 64 (layer1), >= 4 tiles per wave -> v50: register-resident weights, persistent waves, no barriers
+//   Cin == 64  otherwise                    -> v38: single patch buffer, 39 KB LDS, four workgroups per CU
 //   Cin == 128 (layer2)                    -> v30: 128 output channels per tile, 4 waves
 //   deeper                                  -> v36: 64 output channels per tile, 8 waves, 3-deep weight ring
 // everything else (stride 2, 1x1, maps narrower than 16 pixels) to the generic implicit GEMM, whose tile is chosen
@@ -840,6 +1174,11 @@ int pick_variant(const ConvArgs& a, int groups) {
     const int Cout = a.Cout;
     if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
+        // layer1 at full size: weights stationary in registers (v50) once every wave of the chip gets >= 4 tiles
+        // (its 7 us weight prologue is per launch); smaller problems stay on the ring kernel
+        if (a.Cin == 64 && Cout == 64 && a.H % 4 == 0 && !a.y_f32 && (long)a.M * (a.H / 4) * (a.W / 16) * groups >= 4096 &&
+            (size_t)a.M * a.H * a.W * a.xcs * 2 < (1ull << 31) && (size_t)a.M * a.H * a.W * a.ycs * 2 < (1ull << 31))
+            return 50;
         if (a.Cin == 64 && Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 38;
         if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
         if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;

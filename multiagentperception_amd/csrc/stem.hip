@@ -19,6 +19,8 @@
 
 namespace {
 
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
 constexpr int PATCH_ROWS = 21;     // 2*8 + 5 input rows for 8 output rows
 constexpr int PATCH_COLS = 72;     // 2*32 + 6 (+2 pad) input cols for 32 output cols (+ zero tap)
 constexpr int PATCH_BYTES = PATCH_ROWS * PATCH_COLS * 8;
@@ -157,40 +159,52 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 // it as bf16 in LDS, pools 3x3/2 there and writes only the pooled 4 x 16 pixels.  ReLU outputs are
 // >= 0 and every pooling window holds at least one in-image pixel, so out-of-image conv pixels are
 // staged as 0 instead of -inf (identical maxima).
-constexpr int FP_ROWS = 23;        // input rows for 9 conv rows: 2*8 + 7
+// BAND = conv rows a workgroup owns (8 or 4): BAND + 1 rows are computed per step (the row above is recomputed).
+// BAND 8: 9/8 recompute but 89 KB of LDS at Cout 128 -> one workgroup per CU, whose phases (patch store, MFMA,
+// BN/ReLU staging, pooling) run one after the other on every SIMD; BAND 4: 5/4 recompute, 51 KB -> two
+// workgroups per CU whose phases overlap (measured with tools/stem_phases.py).
 constexpr int FP_COLS = 72;
-constexpr int FP_BYTES = FP_ROWS * FP_COLS * 8;
+template <int BAND> constexpr int fp_rows() { return 2 * BAND + 7; }      // input rows for BAND + 1 conv rows
+template <int BAND> constexpr int fp_bytes() { return fp_rows<BAND>() * FP_COLS * 8; }
 
 // U8 = true: `x` holds the camera frames as the reference's loader reads them -- u8 RGB, [B][N][H][W][3] -- and the
 // loader's transform (airsim_loader.py:521-527: RGB->BGR, float64 (v - mean)/255, cast to f32) is applied while the
 // patch is staged, in double precision, so the bf16 patch is bit-identical to staging the transformed f32 frames.
 struct FrameMean { double m[3]; };   // BGR means
 
-template <int COUT, bool U8>
+#ifdef W2C_STEM_TIMING
+__device__ unsigned long long g_stem_phase[8];
+#define STEM_T(i) do { const long long t_ = clock64(); t_acc[i] += (unsigned long long)(t_ - t_prev); t_prev = t_; } while (0)
+#else
+#define STEM_T(i) do {} while (0)
+#endif
+
+template <int COUT, bool U8, int BAND>
 __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
                                                         const uint16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         uint16_t* __restrict__ y) {
+    constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>(), CR = BAND + 1;   // CR = conv rows per step
     constexpr int CT = COUT / 32;           // channel tiles
     constexpr int NPART = 8 / CT;           // pixel-tile partitions across waves (2 or 4)
-    constexpr int MT_MAX = (9 + NPART - 1) / NPART + (NPART == 2 ? 0 : 0);   // 5 or 3
+    constexpr int MT_MAX = (CR + NPART - 1) / NPART;
     constexpr int ROWBYTES = COUT * 2;      // staged bytes per conv pixel
     constexpr int CHUNKS = ROWBYTES / 16;
     constexpr int SCOLS = 33;               // staged columns: [carry | 32 new]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2* patch = reinterpret_cast<uint2*>(smem);
-    char* stg = smem + FP_BYTES;            // [9][33][COUT] bf16, 16-B chunks swizzled by (col & (CHUNKS-1))
+    char* stg = smem + FP_BYTES;            // [CR][33][COUT] bf16, 16-B chunks swizzled by (col & (CHUNKS-1))
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ct = wave % CT, part = wave / CT;
-    const int mt_lo = (9 * part) / NPART, mt_hi = (9 * (part + 1)) / NPART;      // this wave's conv rows [mt_lo, mt_hi)
+    const int mt_lo = (CR * part) / NPART, mt_hi = (CR * (part + 1)) / NPART;      // this wave's conv rows [mt_lo, mt_hi)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1, Hp = H >> 2, Wp = W >> 2;
     const int img = blockIdx.y;
     const int agent = img / B, b = img - agent * B;
-    const int oy0 = blockIdx.x * 8;
+    const int oy0 = blockIdx.x * BAND;
     const float* xin = U8 ? nullptr : reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
     const uint8_t* xin8 = U8 ? reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3 : nullptr;
 
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
         e_sc[q] = *reinterpret_cast<const f32x4_t*>(scale + ct * 32 + 8 * q + 4 * lhi);
         e_sh[q] = *reinterpret_cast<const f32x4_t*>(shift + ct * 32 + 8 * q + 4 * lhi);
     }
-    constexpr int FILL = (FP_ROWS * FP_COLS + 511) / 512;               // 4
+    constexpr int FILL = (FP_ROWS * FP_COLS + 511) / 512;
     float pv[FILL][3];
     unsigned pmask = 0;
     auto load_patch = [&](int ox0) {
@@ -250,14 +264,21 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
     };
 
     // carry column (conv column -1) of the first step is outside the image: zeros
-    for (int i = tid; i < 9 * CHUNKS; i += 512)
+    for (int i = tid; i < CR * CHUNKS; i += 512)
         *reinterpret_cast<uint4*>(stg_addr(i / CHUNKS, 0, i % CHUNKS)) = make_uint4(0, 0, 0, 0);
 
     load_patch(0);
+#ifdef W2C_STEM_TIMING
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = clock64();
+#endif
     for (int ox0 = 0; ox0 < Wo; ox0 += 32) {
         store_patch();
+        STEM_T(0);
         __syncthreads();                    // patch visible; previous step's pooling reads + carry copy are done
+        STEM_T(1);
         if (ox0 + 32 < Wo) load_patch(ox0 + 32);
+        STEM_T(2);
 
         f32x16_t acc[MT_MAX];
 #pragma unroll
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
                 }
             }
         }
+        STEM_T(3);
         // BN + ReLU -> bf16 -> staging[mt][1 + l31][channels]; conv row oy0-1+mt < 0 is outside the image
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -291,19 +313,22 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = inimg ? fmaxf(acc[m][4 * q + r] * sc[r] + sh[r], 0.f) : 0.f;
+                    // sign bit cleared: a -0 out of fmaxf would order above every positive value in the u16 max below
                     *reinterpret_cast<uint2*>(stg_addr(mt, 1 + l31, ct * 4 + q) + lhi * 8) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        make_uint2(pack_bf16x2(v[0], v[1]) & 0x7FFF7FFFu, pack_bf16x2(v[2], v[3]) & 0x7FFF7FFFu);
                 }
             }
         }
+        STEM_T(4);
         __syncthreads();
+        STEM_T(5);
         // pool 3x3/2: pooled (pyl, pxl) <- staged rows 2*pyl..2*pyl+2, staged cols 2*pxl..2*pxl+2
-        for (int id = tid; id < 64 * CHUNKS; id += 512) {
+        for (int id = tid; id < (BAND / 2) * 16 * CHUNKS; id += 512) {
             const int cg = id % CHUNKS, pp = id / CHUNKS;
             const int pyl = pp >> 4, pxl = pp & 15;
-            float best[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) best[e] = 0.f;
+            // staged values are ReLU outputs (>= 0, never -0: fmaxf(x, 0.f) of a negative is +0), and non-negative bf16
+            // order like their bit patterns: the 3x3 max is a packed unsigned 16-bit max, no unpacking.
+            u16x2_t best[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -312,24 +337,30 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
                     const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        best[2 * e] = fmaxf(best[2 * e], bf16_to_f32((uint16_t)(wv[e] & 0xFFFFu)));
-                        best[2 * e + 1] = fmaxf(best[2 * e + 1], bf16_to_f32((uint16_t)(wv[e] >> 16)));
+                        const u16x2_t t = __builtin_bit_cast(u16x2_t, wv[e]);
+                        best[e] = __builtin_elementwise_max(best[e], t);
                     }
                 }
             uint4 o;
-            o.x = pack_bf16x2(best[0], best[1]); o.y = pack_bf16x2(best[2], best[3]);
-            o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
+            o.x = __builtin_bit_cast(uint32_t, best[0]); o.y = __builtin_bit_cast(uint32_t, best[1]);
+            o.z = __builtin_bit_cast(uint32_t, best[2]); o.w = __builtin_bit_cast(uint32_t, best[3]);
             const int py = (oy0 >> 1) + pyl, px = (ox0 >> 1) + pxl;
             *reinterpret_cast<uint4*>(y + (((size_t)img * Hp + py) * Wp + px) * COUT + cg * 8) = o;
         }
+        STEM_T(6);
         __syncthreads();
         // carry: staged column 32 (conv column ox0+31) becomes column 0 of the next step
-        for (int i = tid; i < 9 * CHUNKS; i += 512) {
+        for (int i = tid; i < CR * CHUNKS; i += 512) {
             const int row = i / CHUNKS, cg = i % CHUNKS;
             *reinterpret_cast<uint4*>(stg_addr(row, 0, cg)) = *reinterpret_cast<const uint4*>(stg_addr(row, 32, cg));
         }
+        STEM_T(7);
         // (ordered before the next step's staging writes by the barrier after store_patch)
     }
+#ifdef W2C_STEM_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stem_phase[i], t_acc[i]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, int M, int H, int W, int C,
@@ -388,6 +419,14 @@ int launch_stem(const float* x, int B, int N, int H, int W, const uint16_t* w, c
 
 }  // namespace
 
+#ifdef W2C_STEM_TIMING
+extern "C" int w2c_debug_stem_phases(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stem_phase), 64) != hipSuccess) return W2C_E_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stem_phase), z, 64) != hipSuccess) return W2C_E_LAUNCH; }
+    return W2C_OK;
+}
+#endif
+
 extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int W,
                                         const uint16_t* w, const float* scale, const float* shift, int Cout,
                                         uint16_t* y, w2c_stream_t stream) {
@@ -400,21 +439,31 @@ extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int
     return W2C_E_ARG;
 }
 
-template <int COUT, bool U8>
-static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
-                     const float* shift, uint16_t* y, hipStream_t s) {
-    constexpr int lds = FP_BYTES + 9 * 33 * COUT * 2;
+template <int COUT, bool U8, int BAND>
+static int launch_stem_pool_band(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+                                 const float* shift, uint16_t* y, hipStream_t s) {
+    constexpr int lds = fp_bytes<BAND>() + (BAND + 1) * 33 * COUT * 2;
     static unsigned long long attr_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT, U8>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT, U8, BAND>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
-    dim3 grid((H / 2) / 8, N * B);
-    hipLaunchKernelGGL((stem_pool_kernel<COUT, U8>), grid, dim3(512), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
+    dim3 grid((H / 2) / BAND, N * B);
+    hipLaunchKernelGGL((stem_pool_kernel<COUT, U8, BAND>), grid, dim3(512), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
     return w2c_launch_status();
+}
+
+template <int COUT, bool U8>
+static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+                            const float* shift, uint16_t* y, hipStream_t s) {
+    static const int band = [] { const char* e = getenv("W2C_STEM_BAND"); return e ? atoi(e) : 8; }();
+    // measured (tools/bench_stem.py, cfg 2): BAND 8 143 us, BAND 4 154 us -- the second resident workgroup does not pay
+    // for its 5/4 recompute; W2C_STEM_BAND=4 keeps the A/B reproducible.
+    if (band == 4) return launch_stem_pool_band<COUT, U8, 4>(x, mean, B, N, H, W, w, scale, shift, y, s);
+    return launch_stem_pool_band<COUT, U8, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);
 }
 
 extern "C" int w2c_stem_conv7x7_bn_relu_maxpool(const float* x, int B, int N, int H, int W,

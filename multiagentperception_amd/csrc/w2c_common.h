@@ -8,6 +8,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
 
 // global / LDS address-space pointer casts for the LDS-DMA builtin
 #define W2C_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -15,14 +17,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // f32 -> bf16 round-to-nearest-even (finite inputs; activations never NaN by construction,
 // NaN still maps to a NaN pattern because the mantissa carry cannot clear the exponent).
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer
+// add-and-shift idiom costs ~9 VALU per pair and made the conv / stem epilogues VALU-bound).
+typedef float w2c_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 w2c_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const w2c_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, w2c_bf16x2_t));
 }
 
 // Last HIP error text of the calling thread (for w2c_last_error_string()).

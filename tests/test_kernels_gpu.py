@@ -128,6 +128,9 @@ VARIANT_CASES = [
     (33, 3, 4, 32, 128, 64, 3, 1, 2, True), (34, 1, 24, 16, 64, 64, 3, 1, 1, True),
     (38, 3, 16, 32, 64, 64, 3, 1, 2, True), (39, 2, 8, 16, 64, 128, 3, 1, 1, False),
     (35, 2, 8, 32, 128, 128, 3, 1, 2, True), (36, 1, 16, 16, 192, 64, 3, 1, 1, False), (37, 2, 16, 16, 64, 256, 3, 1, 1, True),
+    # layer1 register-resident-weights kernel: borders on every side, single-tile images, both groups, +/- residual
+    (50, 3, 16, 32, 64, 64, 3, 1, 2, True), (50, 2, 4, 16, 64, 64, 3, 1, 1, False), (50, 5, 12, 48, 64, 64, 3, 1, 2, False),
+    (50, 1, 64, 64, 64, 64, 3, 1, 1, True),
 ]
 
 
@@ -212,7 +215,7 @@ def test_conv_splitk_matches_fp32_and_is_deterministic(case):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
 
 
-@pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (31, 64, 64, 128), (36, 64, 64, 128), (38, 64, 64, 128),
+@pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (31, 64, 64, 128), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128),
                                                  (33, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16)])
 def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
     """Regression for a WAR race of the LDS pipeline: a raw s_barrier let waves pass with fragment reads still in

@@ -1,0 +1,38 @@
+"""Phase cycles of the layer1 register-resident-weights conv (variant 50), from its p.dbg accumulators."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multiagentperception_amd import ops, _native  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    M, H, W, G = 20, 128, 128, 2
+    x = torch.randn(M, H, W, G * 64, device=dev).to(torch.bfloat16)
+    w = (torch.randn(G, 64, 576, device=dev) * 0.05).to(torch.bfloat16)
+    sc = torch.ones(G * 64, device=dev)
+    sh = torch.zeros(G * 64, device=dev)
+    r = torch.randn(M, H, W, G * 64, device=dev).to(torch.bfloat16)
+    for res in (r, None):
+        for _ in range(3):
+            ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, variant=50)
+        buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+        _native.lib().w2c_debug_conv_timeline(buf.data_ptr())
+        ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, variant=50)
+        torch.cuda.synchronize()
+        full = buf.view(-1, 8).cpu()
+        full = full[full[:, 7] == 1]
+        t0 = full[:, 4].min()
+        wl = (full[:, 4:7] - t0).double() / 100.0     # us
+        print("   wall (us): kernel start spread %.1f | prologue mean %.1f | tile loop mean %.1f max %.1f | last end %.1f" % (
+            wl[:, 0].max(), (wl[:, 1] - wl[:, 0]).mean(), (wl[:, 2] - wl[:, 1]).mean(), (wl[:, 2] - wl[:, 1]).max(), wl[:, 2].max()))
+        b = full[:, :4].double()
+        tiles = M * (H // 4) * (W // 16) * G / (b.shape[0] * 4)
+        print("residual=%s: %d workgroups, %.1f tiles/wave; cycles per tile: DMA issue %.0f | MFMA loop %.0f (pure 4608) | "
+              "vmcnt wait %.0f | epilogue %.0f | total %.0f" % (res is not None, b.shape[0], tiles, *(b.mean(0) / tiles).tolist(),
+                                                                 b.sum(1).mean() / tiles))
+
+
+if __name__ == "__main__":
+    main()
