@@ -181,6 +181,36 @@ def test_fused_evaluator_path_u8_frames_to_label_maps(graph):
         np.testing.assert_array_equal(np.asarray(s1[k]), np.asarray(s2[k]))
 
 
+@pytest.mark.parametrize("mode", ["activated", "argmax_test"])
+def test_sparse_handshake_path_equals_dense_forward(mode):
+    """SURVEY 8f rank 1 on one rank: (a) the handshake-ordered code path reproduces forward() exactly; (b) zeroing every
+    value map whose fusion weight is 0 for all query agents -- what a peer would NOT have sent -- changes nothing."""
+    from multiagentperception_amd import engine as _engine, ops
+    from multiagentperception_amd.parallel import AgentParallelForward
+    case = CASES[0]
+    model, _ = _build(case)
+    b, n, s = case["batch"], case["agent_num"], case["size"]
+    x = torch.from_numpy(filler.synthetic_frames(b, n, s, s, case["seed"])).cuda()
+    ref = model(x, training=False, MO_flag=True, inference=mode)
+    fwd = AgentParallelForward(model)
+    eng = model._engine_for(x, _engine.CommEngine)
+    with torch.no_grad():
+        sq = eng.trunk.run(x, n)
+        pred, prob, action, nnz = fwd._sparse(eng, sq, b, n, mode)
+        assert torch.equal(pred, ref[0]) and torch.equal(prob, ref[1]) and torch.equal(action, ref[2])
+        assert fwd.last_exchange == (0, 0)
+        keys, querys = eng.policy_tail(sq)
+        _, coef, _, _ = ops.comm_graph_projected(querys, keys, b, n, eng.who, mode)
+        used = (coef != 0).any(dim=2)                                    # [B, N_keys]
+        v = sq[..., :eng.feat].contiguous()
+        for k in range(n):
+            for bb in range(b):
+                if not bool(used[bb, k]):
+                    v[k * b + bb].zero_()
+        pred2, prob2, _, _, _ = eng.graph_and_decode(v, keys, querys, b, n, 0, n, mode)
+        assert torch.equal(pred2, ref[0]) and torch.equal(prob2, ref[1])
+
+
 def test_hip_graph_replay_equals_eager_bit_for_bit():
     """W2C_HIP_GRAPH path: the captured middle of the forward must reproduce the eager launches exactly,
     on the capture input AND on a different input of the same shape (static-buffer plumbing)."""

@@ -131,6 +131,8 @@ VARIANT_CASES = [
     # layer1 register-resident-weights kernel: borders on every side, single-tile images, both groups, +/- residual
     (50, 3, 16, 32, 64, 64, 3, 1, 2, True), (50, 2, 4, 16, 64, 64, 3, 1, 1, False), (50, 5, 12, 48, 64, 64, 3, 1, 2, False),
     (50, 1, 64, 64, 64, 64, 3, 1, 1, True),
+    # layer2 sibling (shared patch, one barrier per tile): single- and multi-tile workgroups
+    (51, 3, 16, 32, 128, 128, 3, 1, 2, True), (51, 2, 4, 16, 128, 128, 3, 1, 1, False), (51, 9, 32, 64, 128, 128, 3, 1, 2, True),
 ]
 
 
@@ -215,7 +217,7 @@ def test_conv_splitk_matches_fp32_and_is_deterministic(case):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
 
 
-@pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (31, 64, 64, 128), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128),
+@pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (31, 64, 64, 128), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128), (51, 128, 128, 64),
                                                  (33, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16)])
 def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
     """Regression for a WAR race of the LDS pipeline: a raw s_barrier let waves pass with fragment reads still in

@@ -89,3 +89,64 @@ def test_shard_agents_rejects_uneven_split():
     assert parallel.shard_agents(16, 8, 3) == (6, 2)
     with pytest.raises(ValueError):
         parallel.shard_agents(5, 2, 0)
+
+
+def _sparse_worker(rank, world, port, N, B, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiagentperception_amd import parallel
+    n_loc = N // world
+    gen = torch.Generator().manual_seed(5)                       # identical on both ranks: the graph every rank derives
+    need = torch.rand(B, N, N, generator=gen) > 0.55
+    need[:, 0, :] = False                                        # an agent nobody listens to
+    v_full = torch.randn(N * B, 4, 4, 8, generator=gen).to(torch.bfloat16)      # agent-major value maps
+    v_loc = v_full[rank * n_loc * B:(rank + 1) * n_loc * B].contiguous()
+    v_all, got, dense = parallel.sparse_exchange(v_loc, need, B, N)
+    torch.save(dict(v_all=v_all.float(), got=got, dense=dense), os.path.join(out_dir, "sparse%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,B", [(4, 2), (6, 1)])
+def test_sparse_handshake_exchange_moves_exactly_the_used_value_maps(tmp_path, N, B):
+    """only value maps with a non-zero fusion weight for some query agent of the receiving rank cross
+    the wire; every row a rank will read is bit-exact, every other remote row is zero (weight 0 in the fusion)."""
+    world = 2
+    mp.spawn(_sparse_worker, args=(world, _free_port(), N, B, str(tmp_path)), nprocs=world, join=True)
+    gen = torch.Generator().manual_seed(5)
+    need = torch.rand(B, N, N, generator=gen) > 0.55
+    need[:, 0, :] = False
+    v_full = torch.randn(N * B, 4, 4, 8, generator=gen).to(torch.bfloat16).float()
+    n_loc = N // world
+    total_got = 0
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), "sparse%d.pt" % r))
+        want_rows = 0
+        for k in range(N):
+            for b in range(B):
+                row = k * B + b
+                local = r * n_loc <= k < (r + 1) * n_loc
+                used = bool(need[b, k, r * n_loc:(r + 1) * n_loc].any())
+                if local or used:
+                    np.testing.assert_array_equal(d["v_all"][row].numpy(), v_full[row].numpy())
+                else:
+                    assert float(d["v_all"][row].abs().max()) == 0.0
+                want_rows += int(used and not local)
+        assert d["got"] == want_rows and d["dense"] == (world - 1) * n_loc * B
+        total_got += d["got"]
+    assert 0 < total_got < world * (world - 1) * n_loc * B          # strictly fewer maps than the all-gather moves
+
+
+def test_sparse_plan_is_consistent_between_the_two_ends():
+    from multiagentperception_amd import parallel
+    gen = torch.Generator().manual_seed(9)
+    B, N, world = 3, 8, 4
+    need = torch.rand(B, N, N, generator=gen) > 0.7
+    plans = [parallel.plan_sparse_exchange(need, B, N, world, r) for r in range(world)]
+    n_loc = N // world
+    for r in range(world):
+        for s in range(world):
+            send_local = plans[r][0][s]                              # rows of r's shard that go to s
+            recv_global = plans[s][1][r]                             # rows s expects from r
+            assert [r * n_loc * B + i for i in send_local] == recv_global

@@ -33,12 +33,12 @@ VALID = {  # variant -> (BM, BN, BK)
     12: (128, 128, 32), 13: (64, 64, 64), 14: (128, 64, 64), 15: (256, 64, 64),
     20: (256, 128, 64), 21: (256, 128, 64), 22: (256, 64, 64), 23: (256, 128, 64), 24: (256, 64, 64), 25: (256, 64, 64),
     26: (256, 128, 64),
-    38: (128, 64, 64), 39: (128, 64, 64), 50: (64, 64, 64),
+    38: (128, 64, 64), 39: (128, 64, 64), 50: (64, 64, 64), 51: (64, 128, 64),
     35: (128, 128, 64), 36: (128, 64, 64), 37: (128, 128, 64),
     30: (128, 128, 64), 31: (128, 64, 64), 32: (128, 128, 64), 33: (128, 64, 64), 34: (128, 64, 64),
 }
 PATCH_GEOM = {20: (8, 32), 21: (8, 32), 22: (8, 32), 23: (16, 16), 24: (16, 16), 25: (8, 32), 26: (16, 16),
-              38: (8, 16), 39: (8, 16), 50: (4, 16),
+              38: (8, 16), 39: (8, 16), 50: (4, 16), 51: (4, 16),
               35: (8, 16), 36: (8, 16), 37: (8, 16),
               30: (8, 16), 31: (8, 16), 32: (4, 32), 33: (4, 32), 34: (8, 16)}
 
@@ -65,7 +65,7 @@ def main():
         cells = []
         for v in variants:
             bm, bn, bk = VALID[v]
-            if (v in (38, 39, 50) and cin != 64) or (v == 50 and cout != 64) or cout % bn or cin % bk or (v in PATCH_GEOM and (ks != 3 or st != 1 or H % PATCH_GEOM[v][0] or W % PATCH_GEOM[v][1])):
+            if (v in (38, 39, 50) and cin != 64) or (v == 50 and cout != 64) or (v == 51 and (cin != 128 or cout != 128)) or cout % bn or cin % bk or (v in PATCH_GEOM and (ks != 3 or st != 1 or H % PATCH_GEOM[v][0] or W % PATCH_GEOM[v][1])):
                 cells.append("%16s" % "-")
                 continue
             try:

@@ -8,18 +8,20 @@ from multiagentperception_amd import ops, _native  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    M, H, W, G = 20, 128, 128, 2
-    x = torch.randn(M, H, W, G * 64, device=dev).to(torch.bfloat16)
-    w = (torch.randn(G, 64, 576, device=dev) * 0.05).to(torch.bfloat16)
-    sc = torch.ones(G * 64, device=dev)
-    sh = torch.zeros(G * 64, device=dev)
-    r = torch.randn(M, H, W, G * 64, device=dev).to(torch.bfloat16)
+    variant = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    C, H = (64, 128) if variant == 50 else (128, 64)
+    M, W, G = 20, H, 2
+    x = torch.randn(M, H, W, G * C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(G, C, 9 * C, device=dev) * 0.05).to(torch.bfloat16)
+    sc = torch.ones(G * C, device=dev)
+    sh = torch.zeros(G * C, device=dev)
+    r = torch.randn(M, H, W, G * C, device=dev).to(torch.bfloat16)
     for res in (r, None):
         for _ in range(3):
-            ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, variant=50)
+            ops.conv_igemm(x, 0, C, w, C, 3, 1, G, sc, sh, residual=res, variant=variant)
         buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
         _native.lib().w2c_debug_conv_timeline(buf.data_ptr())
-        ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, variant=50)
+        ops.conv_igemm(x, 0, C, w, C, 3, 1, G, sc, sh, residual=res, variant=variant)
         torch.cuda.synchronize()
         full = buf.view(-1, 8).cpu()
         full = full[full[:, 7] == 1]
@@ -28,7 +30,7 @@ def main():
         print("   wall (us): kernel start spread %.1f | prologue mean %.1f | tile loop mean %.1f max %.1f | last end %.1f" % (
             wl[:, 0].max(), (wl[:, 1] - wl[:, 0]).mean(), (wl[:, 2] - wl[:, 1]).mean(), (wl[:, 2] - wl[:, 1]).max(), wl[:, 2].max()))
         b = full[:, :4].double()
-        tiles = M * (H // 4) * (W // 16) * G / (b.shape[0] * 4)
+        tiles = M * (H // 4) * (W // 16) * G / (b.shape[0] * (4 if variant == 50 else 1))
         print("residual=%s: %d workgroups, %.1f tiles/wave; cycles per tile: DMA issue %.0f | MFMA loop %.0f (pure 4608) | "
               "vmcnt wait %.0f | epilogue %.0f | total %.0f" % (res is not None, b.shape[0], tiles, *(b.mean(0) / tiles).tolist(),
                                                                  b.sum(1).mean() / tiles))
