@@ -44,7 +44,9 @@ def _pack_w(conv_weight):
 class ConvPlan:
     """One w2c_conv_igemm_bf16 call: `groups` same-shape convs side by side."""
 
-    def __init__(self, convs, bns=None, biases=None, relu=True, pad_cout_to=None):
+    def __init__(self, convs, bns=None, biases=None, relu=True, pad_cout_to=None, in_perm=None):
+        """in_perm: optional input-channel permutation applied to the weights (the producer wrote its channels in that
+        order)."""
         c0 = convs[0]
         self.groups = len(convs)
         self.cin = c0.in_channels
@@ -54,7 +56,7 @@ class ConvPlan:
         self.relu = relu
         ws, scs, shs = [], [], []
         for i, c in enumerate(convs):
-            w = _pack_w(c.weight)
+            w = _pack_w(c.weight if in_perm is None else c.weight[:, in_perm])
             if bns is not None:
                 sc, sh = _fold_bn(bns[i], c.bias)
             else:
@@ -175,9 +177,9 @@ class HeadPlan:
 
 
 class DecoderPlan:
-    def __init__(self, decoder, n_classes):
+    def __init__(self, decoder, n_classes, in_perm=None):
         pred = decoder.output_decoder.pred
-        self.c0 = ConvPlan([pred[0]], relu=True)
+        self.c0 = ConvPlan([pred[0]], relu=True, in_perm=in_perm)
         self.c2 = ConvPlan([pred[2]], relu=False, pad_cout_to=32)
         self.n_classes = n_classes
 
@@ -299,3 +301,69 @@ class SingleEngine:
         feat = self.trunk.run(x, 1)          # N=1: image index == batch index
         pred, low = self.decoder.run(feat)
         return pred, low, feat
+
+
+
+class SRMSEngine:
+    """LearnWhen2Com / LearnWho2Com (single requester = agent 0, five agents hard-coded: agent.py:556,766) on the same
+    kernels.  'unified': one value encoder for all five agents, run side by side with the policy encoder.
+    'only_normal_agents' (agent.py:823-830): the policy encoder + normal_encoder run side by side on all five frames
+    (agent 0's normal-encoder map is unused) and degarded_encoder runs alone on the requester's frames."""
+
+    N = 5
+
+    def __init__(self, model):
+        self.who = bool(model._who)
+        self.has_query = bool(model.has_query)
+        self.n_classes = model.n_classes
+        self.feat = 512
+        pn = model.query_key_net
+        enc = model.shared_img_encoder
+        if enc == "unified":
+            self.trunk = TrunkPlan([model.u_encoder, pn.img_encoder])
+            self.trunk0 = None
+        elif enc == "only_normal_agents":
+            self.trunk = TrunkPlan([model.normal_encoder, pn.img_encoder])
+            self.trunk0 = TrunkPlan([model.degarded_encoder])
+        else:
+            raise ops.W2CError("shared_img_encoder=%r (five separate encoders, agent.py:832-836) is not on the HIP path; no "
+                               "reference config selects it" % (enc,))
+        self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
+                       for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
+        self.heads = None
+        self._model_heads = (model.key_net, model.query_net if self.has_query else None)
+        self.wq = model.attention_net.linear.weight.detach().float().contiguous()
+        self.bq = model.attention_net.linear.bias.detach().float().contiguous()
+        # LearnWho2Com decodes cat(own, fused) (agent.py:612); w2c_fuse_values writes (fused, own)
+        perm = torch.cat([torch.arange(512, 1024), torch.arange(0, 512)]).to(self.wq.device) if self.who else None
+        self.decoder = DecoderPlan(model.decoder, self.n_classes, in_perm=perm)
+
+    def forward(self, x, mode):
+        """x f32 [B,15,H,W] -> pred f32 [B,n_cls,H,W], prob [B,K,1] (K = 5, or 4 for who), coef [B,K,1], action [B,1], nnz [B]."""
+        B, N = x.shape[0], self.N
+        sq = self.trunk.run(x, N)                                       # [5B,h,w,1024]: V | policy map
+        if self.trunk0 is not None:
+            v = sq[..., :self.feat].contiguous()
+            v[:B] = self.trunk0.run(x[:, 0:3].contiguous(), 1)
+            vcs_src = v
+        else:
+            vcs_src = sq
+        y = self.policy[0].run(sq, x_ch_off=self.feat)
+        for c in self.policy[1:]:
+            y = c.run(y)
+        if self.heads is None:
+            self.heads = HeadPlan([h for h in self._model_heads if h is not None], y.shape[1] * y.shape[2],
+                                  key_projection=(self.wq, self.bq))
+        outs = self.heads.run(y)
+        tproj = outs[0]                                                 # [5B, Dq+1] projected keys, agent-major
+        query = outs[1][:B].contiguous() if self.has_query else None    # the requester's queries (agent 0)
+        if self.who:
+            prob, coef, action, nnz = ops.comm_graph_projected(query, tproj[B:].contiguous(), B, N - 1, False, mode,
+                                                               tie_bias=0.0, q_lo=0, q_n=1)
+            coef5 = torch.cat([torch.zeros_like(coef[:, :1]), coef], 1).contiguous()       # requester's own map: weight 0
+        else:
+            prob, coef, action, nnz = ops.comm_graph_projected(query, tproj, B, N, False, mode, tie_bias=0.0, q_lo=0, q_n=1)
+            coef5 = coef
+        fused = ops.fuse_values(vcs_src, self.feat, coef5, B, N, 0, 1, append_own=self.who)
+        low = self.decoder.low_logits(fused)
+        return ops.upsample_bilinear32(low, self.n_classes), prob, coef, action, nnz

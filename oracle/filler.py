@@ -74,7 +74,9 @@ def _gain(name, fan_in=None):
     if name.endswith("query_net.fc.4.weight"):
         return 1.5
     if name.endswith("attention_net.linear.weight"):
-        return 2.0
+        # the single-request configs use 8-d queries (srms_when2com.yml): the same gain leaves softmax_k ~ uniform
+        # (every P within 0.03 of the 0.2 threshold); scale with (32/Dq)^0.75 so P is as peaked as in the 32-d fixtures
+        return 2.0 if fan_in is None or fan_in >= 32 else 2.0 * (32.0 / fan_in) ** 0.75
     # second BN of every BasicBlock: damp the residual branch so the trunk's
     # variance does not double per block with eval-mode (non-normalising) BN.
     if ".bn2.weight" in name:

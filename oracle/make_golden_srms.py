@@ -1,0 +1,123 @@
+"""Golden vectors for the single-request models: LearnWhen2Com / LearnWho2Com.
+
+TEST INFRASTRUCTURE.  Imports the reference from /root/reference (this container only, via the stubs of
+oracle/make_golden.py), fills it with the deterministic filler, runs its forward on the synthetic frames and writes
+tests/golden/srms_*.npz + cases_srms.json + state_spec_srms.json.  Also checks the oracle restatement
+(oracle/when2com_oracle.py learnwhen2com_forward / learnwho2com_forward) against the reference while it is loaded.
+
+    python oracle/make_golden_srms.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import filler, make_golden as mg  # noqa: E402
+from oracle import when2com_oracle as orc  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+import diag_forward as diag  # noqa: E402
+
+GOLD = mg.GOLD
+MARGIN = 0.04
+CASES = [
+    # name, arch, yml, encoder, batch, size, modes, seed, overrides
+    ("srms_when_uni_b2_128", "LearnWhen2Com", "single-request-multiple-support/srms_when2com.yml", "unified", 2, 128,
+     ("softmax", "argmax_test", "activated"), 41, {}),
+    ("srms_when_ona_b1_128", "LearnWhen2Com", "single-request-multiple-support/srms_when2com.yml", "only_normal_agents", 1, 128,
+     ("softmax", "argmax_test", "activated"), 42, {}),
+    ("srms_who_uni_b2_128", "LearnWho2Com", "single-request-multiple-support/srms_who2com.yml", "unified", 2, 128,
+     ("softmax", "argmax_test"), 43, {}),
+    ("srms_who_ona_q0_b1_128", "LearnWho2Com", "single-request-multiple-support/srms_who2com.yml", "only_normal_agents", 1, 128,
+     ("softmax", "argmax_test"), 44, {"query": False}),
+]
+
+
+def main():
+    ref_models, ref_metrics = mg.load_reference()
+    metas, specs = [], {}
+    for name, arch, yml, enc, batch, size, modes, seed0, over in CASES:
+        cfg = mg.ref_cfg(yml, 5, size, shared_img_encoder=enc, **over)
+        model = ref_models.get_model(cfg, 11).eval()
+        filler.apply_to_module(model)
+        qsz = cfg["model"]["query_size"]
+        has_query = bool(cfg["model"]["query"])
+        spec = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+        mine = orc.state_spec(arch, image_size=size, has_query=has_query, query_size=qsz, shared_img_encoder=enc)
+        assert [(k, list(sh)) for k, sh in mine] == spec, "state_spec mismatch for " + name
+        sd = orc.to_torch(filler.fill_state_dict(mine))
+        fwd = orc.learnwhen2com_forward if arch == "LearnWhen2Com" else orc.learnwho2com_forward
+        for seed in range(seed0, seed0 + 2000):
+            x = torch.from_numpy(filler.synthetic_frames(batch, 5, size, size, seed))
+            with torch.no_grad():
+                p_try = model(x, training=False, inference="softmax")[1]                  # [B,1,K]
+            top2 = p_try.topk(2, dim=2)[0]
+            if float((p_try - 0.2).abs().min()) >= MARGIN and float((top2[..., 0] - top2[..., 1]).min()) >= MARGIN:
+                # as in make_golden.py: the fixture must be well conditioned for ANY bf16-storage pipeline -- the oracle
+                # with conv operands / ReLU outputs rounded to bf16 has to stay well inside the stated GPU tolerances
+                kw = dict(has_query=has_query, query_size=qsz, shared_img_encoder=enc)
+                r = fwd(sd, x, training=False, inference="softmax", **kw)
+                real_conv, real_relu = orc.F.conv2d, orc.F.relu
+                try:
+                    orc.F.conv2d = lambda inp, w, b=None, **k: real_conv(diag.bf16r(inp), diag.bf16r(w), b, **k)
+                    orc.F.relu = lambda t, *a, **k: diag.bf16r(real_relu(t))
+                    e = fwd(sd, x, training=False, inference="softmax", **kw)
+                finally:
+                    orc.F.conv2d, orc.F.relu = real_conv, real_relu
+                p_err, l_err = float((e[1] - r[1]).abs().max()), diag.rel(e[0], r[0])
+                if p_err <= 1e-2 and l_err <= 8e-3:
+                    break
+        else:
+            raise RuntimeError("no seed with margin for " + name)
+        out = {}
+        labels = filler.synthetic_labels(batch, size, size, seed)
+        meta = dict(name=name, arch=arch, yml=yml, encoder=enc, batch=batch, size=size, seed=seed, modes=list(modes),
+                    emulated_bf16_p_err=p_err, emulated_bf16_logits_rel=l_err,
+                    model_over=over, query_size=qsz, has_query=has_query, n_state=len(spec),
+                    n_param=int(sum(p.numel() for p in model.parameters())))
+        worst = 0.0
+        for mode in modes:
+            grabbed = {}
+            h = model.decoder.output_decoder.pred.register_forward_hook(
+                lambda m, i, o: grabbed.setdefault("low", []).append(o.detach().clone()))
+            with torch.no_grad():
+                res = model(x, training=False, inference=mode)
+            h.remove()
+            pred, prob, action = res[0], res[1], res[2]
+            pre = mode + "_"
+            out.update({pre + "pred_" + k: v for k, v in mg.summarise_logits(pred, seed).items()})
+            out[pre + "low_logits"] = grabbed["low"][-1].numpy()
+            out[pre + "prob"] = prob.numpy()
+            out[pre + "action"] = action.numpy()
+            if len(res) > 3:
+                out[pre + "num_connect"] = np.float64(res[3])
+            rs = ref_metrics.runningScore(11)
+            rs.update(labels, pred.max(1)[1].numpy())
+            out[pre + "miou"] = np.float64(rs.get_scores()[0]["Mean IoU : \t"])
+            # pin the restatement against the reference it restates
+            mine_res = fwd(sd, x, training=False, inference=mode, has_query=has_query, query_size=qsz, shared_img_encoder=enc)
+            worst = max(worst, float((mine_res[0] - pred).abs().max()), float((mine_res[1] - prob).abs().max()))
+            assert torch.equal(mine_res[2].float(), action.float()) or mode == "activated" and \
+                float((mine_res[2] - action).abs().max()) < 1e-6
+            if len(res) > 3:
+                assert abs(float(mine_res[3]) - float(res[3])) < 1e-12
+        meta["oracle_vs_reference_max_abs"] = worst
+        assert worst < 2e-4, (name, worst)
+        p = out[modes[0] + "_prob"]
+        meta["min_dist_to_thres"] = float(np.abs(p - 0.2).min())
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+        metas.append(meta)
+        specs[name] = spec
+        print(json.dumps(meta))
+    with open(os.path.join(GOLD, "cases_srms.json"), "w") as fp:
+        json.dump(metas, fp, indent=1)
+    with open(os.path.join(GOLD, "state_spec_srms.json"), "w") as fp:
+        json.dump(specs, fp)
+
+
+if __name__ == "__main__":
+    main()

@@ -91,7 +91,7 @@ def n_feat_for(image_size):
 
 
 def state_spec(arch, image_size=512, n_classes=N_CLASSES, has_query=True,
-               query_size=32, key_size=1024, feat_channel=512):
+               query_size=32, key_size=1024, feat_channel=512, shared_img_encoder="unified"):
     """Ordered (name, shape) list of the reference module's state_dict.
     Registration order follows the constructors: MIMOcom agent.py:1002-1015,
     MIMOcomWho agent.py:1226-1243, Single_agent agent.py:384-390."""
@@ -113,6 +113,24 @@ def state_spec(arch, image_size=512, n_classes=N_CLASSES, has_query=True,
         e += _mlp_entries("key_net.", nf, key_size) + attn + _decoder_entries("decoder.", 1024, n_classes)
     elif arch == "Single_agent":
         e = _img_encoder_entries("encoder.", feat_channel) + _decoder_entries("decoder.", feat_channel, n_classes)
+    elif arch in ("LearnWhen2Com", "LearnWho2Com"):
+        # registration order: agent.py:692-730 (LearnWhen2Com), agent.py:488-523 (LearnWho2Com)
+        if shared_img_encoder == "unified":
+            e = _img_encoder_entries("u_encoder.", feat_channel)
+        elif shared_img_encoder == "only_normal_agents":
+            e = _img_encoder_entries("degarded_encoder.", feat_channel) + _img_encoder_entries("normal_encoder.", feat_channel)
+        else:
+            e = []
+            for i in range(1, 6):
+                e += _img_encoder_entries("encoder%d." % i, feat_channel)
+        e += policy
+        if has_query:
+            e += _mlp_entries("query_net.", nf, query_size)
+        e += _mlp_entries("key_net.", nf, key_size) + attn
+        if arch == "LearnWhen2Com":
+            e += _decoder_entries("argmax_decoder.", 512, n_classes) + _decoder_entries("decoder.", 512, n_classes)
+        else:
+            e += _decoder_entries("decoder.", 1024, n_classes)
     else:
         raise ValueError("oracle: unknown arch %r" % (arch,))
     return e
@@ -322,6 +340,90 @@ def mimocomwho_forward(sd, inputs, agent_num, training=True, MO_flag=False, infe
         if extras is not None:
             extras.update(low_logits=low2, coef=coef)
         return pred2, prob_action, action, num_connect
+
+
+def _srms_encode(sd, inputs, shared_img_encoder, has_query, query_size):
+    """Shared front of LearnWhen2Com.forward / LearnWho2Com.forward (agent.py:815-862, 566-609): FIVE agents hard-coded
+    (divide_inputs, agent.py:766,556); agent 0 is the requester.  -> V [B,5,512,h,w], keys [B,5,Dk], query [B,1,Dq]."""
+    batch = inputs.shape[0]
+    unified = unify_inputs(inputs, 5)
+    if shared_img_encoder == "unified":
+        feat = img_encoder(unified, sd, "u_encoder.")
+    elif shared_img_encoder == "only_normal_agents":
+        feat = torch.cat((img_encoder(unified[:batch], sd, "degarded_encoder."),
+                          img_encoder(unified[batch:], sd, "normal_encoder.")), 0)
+    else:
+        feat = torch.cat([img_encoder(unified[batch * i:batch * (i + 1)], sd, "encoder%d." % (i + 1)) for i in range(5)], 0)
+    val_mat = _regroup(feat, batch, 5)
+    qk_maps = policy_net4(unified, sd, "query_key_net.")
+    key_mat = _regroup(mlp_head(qk_maps, sd, "key_net."), batch, 5)
+    if has_query:
+        query = mlp_head(qk_maps[:batch], sd, "query_net.").unsqueeze(1)
+    else:
+        query = torch.ones(batch, 1, query_size)
+    return val_mat, key_mat, query
+
+
+def learnwhen2com_forward(sd, inputs, training=True, inference="argmax", has_query=True, query_size=8,
+                          shared_img_encoder="unified", extras=None):
+    """LearnWhen2Com.forward (agent.py:811-889) with GeneralDotProductAttention (agent.py:355-368): the requester
+    (agent 0) attends over all five agents incl. itself; prob_action is [B,1,5]; NO tie-break term."""
+    with torch.no_grad():
+        val_mat, key_mat, query = _srms_encode(sd, inputs, shared_img_encoder, has_query, query_size)
+        prob = torch.softmax(attention_scores(query, key_mat, sd), dim=1)            # [B,5,1], softmax over keys
+        feat = fuse(prob, val_mat)[:, 0]
+        pred, low = simple_decoder(feat, sd, "decoder.")
+        prob_action = prob.transpose(2, 1)                                              # [B,1,5]
+        if extras is not None:
+            extras.update(val_mat=val_mat, key_mat=key_mat, query_mat=query, low_logits=low)
+        action = torch.argmax(prob_action, dim=2)
+        if training:
+            return pred, prob_action, action
+        if inference == "softmax":
+            return pred, prob_action, action, 4
+        if inference == "argmax_test":                                                  # agent.py:774-800
+            sel = val_mat[torch.arange(val_mat.shape[0]), action[:, 0]]
+            num_connect = float((action[:, 0] != 0).sum()) / val_mat.shape[0]
+            pred2, low2 = simple_decoder(sel, sd, "decoder.")
+            if extras is not None:
+                extras.update(low_logits=low2)
+            return pred2, prob_action, action, num_connect
+        if inference == "activated":                                                    # agent.py:802-812
+            act = prob_action * (prob_action > 0.2).float()
+            feat2 = fuse(act.transpose(2, 1), val_mat)[:, 0]
+            num_connect = torch.nonzero(act[:, :, 1:]).shape[0] / val_mat.shape[0]
+            pred2, low2 = simple_decoder(feat2, sd, "decoder.")
+            if extras is not None:
+                extras.update(low_logits=low2)
+            return pred2, prob_action, act, num_connect
+        raise ValueError("Incorrect inference mode")
+
+
+def learnwho2com_forward(sd, inputs, training=True, inference="argmax", has_query=True, query_size=8,
+                         shared_img_encoder="unified", extras=None):
+    """LearnWho2Com.forward (agent.py:564-673): the requester attends over the FOUR other agents; the decoder sees
+    cat(own map, fused map) (1024 channels); prob_action is [B,1,4]; eval returns a 3-tuple."""
+    with torch.no_grad():
+        val_mat, key_mat, query = _srms_encode(sd, inputs, shared_img_encoder, has_query, query_size)
+        own, aux_v, aux_k = val_mat[:, 0], val_mat[:, 1:], key_mat[:, 1:]
+        prob = torch.softmax(attention_scores(query, aux_k, sd), dim=1)                # [B,4,1]
+        aux = fuse(prob, aux_v)[:, 0]
+        pred, low = simple_decoder(torch.cat((own, aux), 1), sd, "decoder.")
+        prob_action = prob.transpose(2, 1)
+        action = torch.argmax(prob_action, dim=2)
+        if extras is not None:
+            extras.update(val_mat=val_mat, key_mat=key_mat, query_mat=query, low_logits=low)
+        if training or inference == "softmax":
+            return pred, prob_action, action
+        if inference == "argmax_test":
+            sel = aux_v[torch.arange(aux_v.shape[0]), action[:, 0]]
+            pred2, low2 = simple_decoder(torch.cat((own, sel), 1), sd, "decoder.")
+            if extras is not None:
+                extras.update(low_logits=low2)
+            return pred2, prob_action, action
+        if inference == "argmax_train":      # decodes with argmax_decoder, which LearnWho2Com never constructs (agent.py:668)
+            raise AttributeError("'LearnWho2Com' object has no attribute 'argmax_decoder'")
+        raise ValueError("Incorrect inference mode")
 
 
 def single_agent_forward(sd, inputs, extras=None):
