@@ -71,7 +71,7 @@ def test_registry_errors_match_reference_shapes():
     with pytest.raises(TypeError):                       # reference: `raise (str)` -> TypeError (models/__init__.py:100-101)
         get_model(_cfg("NoSuchModel"), 11)
     with pytest.raises(NotImplementedError):
-        get_model(_cfg("LearnWhen2Com"), 11)
+        get_model(_cfg("MIMO_All_agents"), 11)           # baselines without attention: outside the path
     with pytest.raises(ValueError, match="Incorrect shared_img_encoder flag"):
         c = _cfg("MIMOcomWho")
         c["model"]["shared_img_encoder"] = False
