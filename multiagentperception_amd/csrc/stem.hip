@@ -179,15 +179,16 @@ __device__ unsigned long long g_stem_phase[8];
 #define STEM_T(i) do {} while (0)
 #endif
 
-template <int COUT, bool U8, int BAND>
-__global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
+template <int COUT, bool U8, int BAND, int NW>
+__global__ __launch_bounds__(64 * NW) void stem_pool_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
                                                         const uint16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         uint16_t* __restrict__ y) {
     constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>(), CR = BAND + 1;   // CR = conv rows per step
     constexpr int CT = COUT / 32;           // channel tiles
-    constexpr int NPART = 8 / CT;           // pixel-tile partitions across waves (2 or 4)
+    constexpr int NT = 64 * NW;             // NW = 8 waves, or 12 so that the BAND + 1 = 9 conv rows split 3/3/3 (no 4-vs-5 wait)
+    constexpr int NPART = NW / CT;          // conv-row partitions across waves
     constexpr int MT_MAX = (CR + NPART - 1) / NPART;
     constexpr int ROWBYTES = COUT * 2;      // staged bytes per conv pixel
     constexpr int CHUNKS = ROWBYTES / 16;
@@ -224,14 +225,14 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
         e_sc[q] = *reinterpret_cast<const f32x4_t*>(scale + ct * 32 + 8 * q + 4 * lhi);
         e_sh[q] = *reinterpret_cast<const f32x4_t*>(shift + ct * 32 + 8 * q + 4 * lhi);
     }
-    constexpr int FILL = (FP_ROWS * FP_COLS + 511) / 512;
+    constexpr int FILL = (FP_ROWS * FP_COLS + NT - 1) / NT;
     float pv[FILL][3];
     unsigned pmask = 0;
     auto load_patch = [&](int ox0) {
         const int iy_base = 2 * oy0 - 5, ix_base = 2 * ox0 - 3;         // conv row oy0-1 needs input row 2*(oy0-1)-3
 #pragma unroll
         for (int f = 0; f < FILL; ++f) {
-            const int pidx = tid + f * 512;
+            const int pidx = tid + f * NT;
             const int r = pidx / FP_COLS, c = pidx - r * FP_COLS;
             const int iy = iy_base + r, ix = ix_base + c;
             const bool ok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
     auto store_patch = [&]() {
 #pragma unroll
         for (int f = 0; f < FILL; ++f) {
-            const int pidx = tid + f * 512;
+            const int pidx = tid + f * NT;
             const bool ok = (pmask >> f) & 1u;
             float v0 = pv[f][0], v1 = pv[f][1], v2 = pv[f][2];
             if constexpr (U8) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
     };
 
     // carry column (conv column -1) of the first step is outside the image: zeros
-    for (int i = tid; i < CR * CHUNKS; i += 512)
+    for (int i = tid; i < CR * CHUNKS; i += NT)
         *reinterpret_cast<uint4*>(stg_addr(i / CHUNKS, 0, i % CHUNKS)) = make_uint4(0, 0, 0, 0);
 
     load_patch(0);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
         __syncthreads();
         STEM_T(5);
         // pool 3x3/2: pooled (pyl, pxl) <- staged rows 2*pyl..2*pyl+2, staged cols 2*pxl..2*pxl+2
-        for (int id = tid; id < (BAND / 2) * 16 * CHUNKS; id += 512) {
+        for (int id = tid; id < (BAND / 2) * 16 * CHUNKS; id += NT) {
             const int cg = id % CHUNKS, pp = id / CHUNKS;
             const int pyl = pp >> 4, pxl = pp & 15;
             // staged values are ReLU outputs (>= 0, never -0: fmaxf(x, 0.f) of a negative is +0), and non-negative bf16
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const void* __restrict__
         STEM_T(6);
         __syncthreads();
         // carry: staged column 32 (conv column ox0+31) becomes column 0 of the next step
-        for (int i = tid; i < CR * CHUNKS; i += 512) {
+        for (int i = tid; i < CR * CHUNKS; i += NT) {
             const int row = i / CHUNKS, cg = i % CHUNKS;
             *reinterpret_cast<uint4*>(stg_addr(row, 0, cg)) = *reinterpret_cast<const uint4*>(stg_addr(row, 32, cg));
         }
@@ -439,7 +440,7 @@ extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int
     return W2C_E_ARG;
 }
 
-template <int COUT, bool U8, int BAND>
+template <int COUT, bool U8, int BAND, int NW>
 static int launch_stem_pool_band(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                                  const float* shift, uint16_t* y, hipStream_t s) {
     constexpr int lds = fp_bytes<BAND>() + (BAND + 1) * 33 * COUT * 2;
@@ -447,12 +448,12 @@ static int launch_stem_pool_band(const void* x, FrameMean mean, int B, int N, in
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT, U8, BAND>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT, U8, BAND, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid((H / 2) / BAND, N * B);
-    hipLaunchKernelGGL((stem_pool_kernel<COUT, U8, BAND>), grid, dim3(512), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
+    hipLaunchKernelGGL((stem_pool_kernel<COUT, U8, BAND, NW>), grid, dim3(64 * NW), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
     return w2c_launch_status();
 }
 
@@ -462,8 +463,11 @@ static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, 
     static const int band = [] { const char* e = getenv("W2C_STEM_BAND"); return e ? atoi(e) : 8; }();
     // measured (tools/bench_stem.py, cfg 2): BAND 8 143 us, BAND 4 154 us -- the second resident workgroup does not pay
     // for its 5/4 recompute; W2C_STEM_BAND=4 keeps the A/B reproducible.
-    if (band == 4) return launch_stem_pool_band<COUT, U8, 4>(x, mean, B, N, H, W, w, scale, shift, y, s);
-    return launch_stem_pool_band<COUT, U8, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);
+    // 12 waves (conv rows split 3/3/3 instead of 4/5): measured 159 us vs 145 us for 8 waves -- kept for the A/B only
+    static const int nw = [] { const char* e = getenv("W2C_STEM_WAVES"); return e ? atoi(e) : 8; }();
+    if (band == 4) return launch_stem_pool_band<COUT, U8, 4, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);
+    if (nw == 12 && COUT == 128) return launch_stem_pool_band<COUT, U8, 8, (COUT == 128 ? 12 : 8)>(x, mean, B, N, H, W, w, scale, shift, y, s);
+    return launch_stem_pool_band<COUT, U8, 8, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);
 }
 
 extern "C" int w2c_stem_conv7x7_bn_relu_maxpool(const float* x, int B, int N, int H, int W,
