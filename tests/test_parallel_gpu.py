@@ -1,0 +1,80 @@
+"""GPU, world_size 2 on ONE device (gloo transport: RCCL refuses two ranks on one GPU): the agent-parallel forward of
+multiagentperception_amd.parallel -- trunk, exchange, local graph columns, fusion, decode -- against the unsharded forward of
+the same model.  Exercises every line the driver's multi-GPU run executes except the RCCL transport itself."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg(n, size):
+    model = dict(arch="MIMOcom", agent_num=n, shared_img_encoder="unified", attention="general", sparse=False, query=True,
+                 query_size=32, key_size=1024, enc_backbone="resnet_encoder", dec_backbone="simple_decoder", feat_squeezer=-1,
+                 feat_channel=512)
+    return {"model": model, "data": {"img_rows": size, "img_cols": size}}
+
+
+def _worker(rank, world, port, N, B, S, seed, mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import filler
+    from ptsemseg.models import get_model
+    from multiagentperception_amd.parallel import AgentParallelForward, shard_agents
+    model = get_model(_cfg(N, S), 11)
+    filler.apply_to_module(model)
+    model = model.to("cuda:0").eval()
+    q_lo, n_loc = shard_agents(N, world, rank)
+    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
+    fwd = AgentParallelForward(model)
+    pred, prob, action, nnz = fwd(x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
+    torch.cuda.synchronize()
+    torch.save(dict(pred=pred.cpu(), prob=prob.cpu(), action=action.cpu(), q_lo=q_lo, n_loc=n_loc,
+                    exch=getattr(fwd, "last_exchange", None)), os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["softmax", "activated", "argmax_test"])
+def test_two_rank_agent_parallel_forward_equals_unsharded(tmp_path, mode):
+    from oracle import filler
+    from ptsemseg.models import get_model
+    world, N, B, S, seed = 2, 4, 2, 128, 321
+    mp.spawn(_worker, args=(world, _free_port(), N, B, S, seed, mode, str(tmp_path)), nprocs=world, join=True)
+    model = get_model(_cfg(N, S), 11)
+    filler.apply_to_module(model)
+    model = model.to("cuda:0").eval()
+    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed)).cuda()
+    pred, prob, action, _ = model(x, training=False, MO_flag=True, inference=mode)
+    pred, prob, action = pred.cpu(), prob.cpu(), action.cpu()
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        lo, n = d["q_lo"], d["n_loc"]
+        # the exchange is exact, but the conv tile variant is chosen from the image count (csrc pick_variant), so a shard
+        # accumulates K in a different order than the full batch: bf16-ulp differences that reach P at the 5e-3 level
+        # (same sensitivity as vs the oracle, tests/test_forward_gpu.py).  Plumbing errors (agent order, rows, columns)
+        # would be O(1).
+        assert float((d["prob"] - prob[:, :, lo:lo + n]).abs().max()) <= 1e-2
+        ref = pred[lo * B:(lo + n) * B]
+        assert d["pred"].shape == ref.shape
+        assert float((d["pred"] - ref).norm() / ref.norm()) <= (2.5e-2 if mode == "activated" else 1e-2)
+        assert float((d["pred"].argmax(1) == ref.argmax(1)).float().mean()) >= 0.98
+        top2 = prob.topk(2, dim=1)[0]
+        if float((top2[:, 0] - top2[:, 1]).min()) > 0.04:
+            assert torch.equal(d["action"], action[:, lo:lo + n])
+        if mode != "softmax":
+            got, dense = d["exch"]
+            assert dense == (world - 1) * n * B and 0 <= got <= dense
