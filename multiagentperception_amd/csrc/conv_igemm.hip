@@ -507,8 +507,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 
     // ---- lock-step pipeline: patch(cc+1) prefetched at tap 0 of chunk cc; weight tiles STAGES-1 ahead ----
     // (Measured and rejected on MI355X, see profiles/r01_b_conv_variant_sweep.txt: an 8-wave "ping-pong"
-    //  variant with wave groups half an epoch apart, a runtime tap loop, and a persistent cross-tile-
-    //  prefetching version with a 32-row multi-pass epilogue -- all slower than this unrolled lock-step form.)
+    //  variant with wave groups half an epoch apart, a runtime tap loop, a persistent cross-tile-
+    //  prefetching version with a 32-row multi-pass epilogue, and asm-pinned MFMAs with the step's DMA pieces
+    //  interleaved between its four MFMA groups (l2 58 -> 63 us, l3 60 -> 67 us) -- all slower than this form.)
 #ifdef W2C_PHASE_TIMING
     long long ph[5] = {0, 0, 0, 0, 0};
 #endif
