@@ -16,6 +16,7 @@
 // in registers for the whole kernel (14 fragments = 56 VGPRs): LDS holds only the input patch
 // and the bf16 output tile, which is written back as whole 256-B (Cout=128) pixel rows.
 #include "w2c_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -364,6 +365,278 @@ __global__ __launch_bounds__(64 * NW) void stem_pool_kernel(const void* __restri
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused stem, second form: pooling in REGISTERS.
+// stem_pool_kernel above stages every conv pixel (9 x 33 x Cout bf16 = 76 KB) in LDS and pools from there; one
+// workgroup fits per CU and its phases (patch store | MFMA | BN/ReLU staging | pooling) run one after the other on
+// every SIMD (tools/stem_phases.py: 11.5 k cycles per step for 4.0 k of MFMA).  Here a workgroup is only Cout/32 waves:
+// wave ct computes ALL 9 conv rows of the 32-column step for its 32 channels (126 MFMAs, weights in 56 registers,
+// accumulators 144), applies BN + ReLU, takes the vertical 3-max in registers, packs to bf16 and takes the horizontal
+// 3-max with two DPP wave shifts (lane = conv column; the column left of the step is carried through 256 B of
+// wave-private LDS), then writes the 4 x 16 pooled pixels of its channels through a 4 KB wave-private staging as
+// 16-byte stores.  LDS per workgroup: double-buffered input patch (26 KB) + 17 KB  =>  two to three workgroups per
+// CU whose phases DO overlap, one barrier per step (patch hand-over).
+__device__ __forceinline__ uint32_t lane_from_left(uint32_t x) {       // lane i <- lane i-1 (wave_shr:1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t lane_from_right(uint32_t x) {      // lane i <- lane i+1 (wave_shl:1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+
+template <int COUT, bool U8>
+__global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) void stem_pool2_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
+                                                            const uint16_t* __restrict__ wpk,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            uint16_t* __restrict__ y) {
+    constexpr int BAND = 8, CR = 9;
+    constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>();
+    constexpr int CT = COUT / 32, NT = 64 * CT;
+    constexpr int WAVE_LDS = 4096 + 256 + 256;                 // pooled staging [64 px][64 B] + carry [2 halves][128 B] + scale|shift
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int Wo = W >> 1, Hp = H >> 2, Wp = W >> 2;
+    const int img = blockIdx.y;
+    const int agent = img / B, b = img - agent * B;
+    const int oy0 = blockIdx.x * BAND;
+    const float* xin = U8 ? nullptr : reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
+    const uint8_t* xin8 = U8 ? reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3 : nullptr;
+    char* const stgw = smem + 2 * FP_BYTES + ct * WAVE_LDS;
+    char* const carry = stgw + 4096;
+
+    bf16x8_t wf[7][2];
+    {
+        const uint16_t* wrow = wpk + (size_t)(ct * 32 + l31) * 224;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[ky][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ky * 32 + (ks * 2 + lhi) * 8);
+        // BN (a*scale + shift) followed by ReLU is monotone in `a` when scale >= 0, so the 3-max can be taken on the raw
+        // accumulators and BN + ReLU applied to a quarter of the values.  A channel with a negative scale gets its weights
+        // negated here (exact: the accumulator is exactly negated) and |scale| below -- bit-identical to BN-then-max.
+        if (scale[ct * 32 + l31] < 0.f) {
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4_t w = __builtin_bit_cast(u32x4_t, wf[ky][ks]);
+                    w ^= u32x4_t{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+                    wf[ky][ks] = __builtin_bit_cast(bf16x8_t, w);
+                }
+        }
+    }
+    // BN scale | shift of this wave's channels in wave-private LDS, in accumulator order: [q][lhi][4] (32 registers saved)
+    char* const ssb = carry + 256;
+    if (lane < 32) {
+        const int q = lane >> 3, hh = (lane >> 2) & 1, k = lane & 3;
+        reinterpret_cast<float*>(ssb)[(q * 2 + hh) * 4 + k] = fabsf(scale[ct * 32 + 8 * q + 4 * hh + k]);
+        reinterpret_cast<float*>(ssb + 128)[(q * 2 + hh) * 4 + k] = shift[ct * 32 + 8 * q + 4 * hh + k];
+    }
+    const char* const ssw = ssb + lhi * 16;                    // + q*32: this lane's 4 scales; +128: shifts
+    constexpr int FILL = (FP_ROWS * FP_COLS + NT - 1) / NT;
+    float pv[FILL][3];
+    unsigned pmask = 0;
+    // a thread stages the same patch positions (row r, column c) at every step; only the image column moves (+64 per
+    // step), so the row offset / row validity are computed once
+    int prow_off[FILL], pcol[FILL];
+#pragma unroll
+    for (int f = 0; f < FILL; ++f) {
+        const int pidx = tid + f * NT;
+        const int r = pidx / FP_COLS, c = pidx - r * FP_COLS;
+        const int iy = 2 * oy0 - 5 + r;
+        const bool rok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H);
+        prow_off[f] = rok ? iy * W : -1;
+        pcol[f] = c - 3;
+    }
+    auto load_patch = [&](int ox0) {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int pidx = tid + f * NT;
+            const int ix = 2 * ox0 + pcol[f];
+            const bool ok = (prow_off[f] >= 0) & (ix >= 0) & (ix < W);
+            const size_t o = ok ? (size_t)(prow_off[f] + ix) : 0;
+            (void)pidx;
+            if constexpr (U8) {
+                pv[f][0] = (float)xin8[o * 3 + 2]; pv[f][1] = (float)xin8[o * 3 + 1]; pv[f][2] = (float)xin8[o * 3];
+            } else {
+                pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];
+            }
+            pmask = ok ? (pmask | (1u << f)) : (pmask & ~(1u << f));
+        }
+    };
+    auto store_patch = [&](uint2* patch) {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int pidx = tid + f * NT;
+            const bool ok = (pmask >> f) & 1u;
+            float v0 = pv[f][0], v1 = pv[f][1], v2 = pv[f][2];
+            if constexpr (U8) {
+                v0 = (float)(((double)v0 - mean.m[0]) / 255.0);
+                v1 = (float)(((double)v1 - mean.m[1]) / 255.0);
+                v2 = (float)(((double)v2 - mean.m[2]) / 255.0);
+            }
+            if (pidx < FP_ROWS * FP_COLS)
+                patch[pidx] = ok ? make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f)) : make_uint2(0u, 0u);
+        }
+    };
+
+    // carry (vertical maxima of conv column -1) of the first step: outside the image -> 0
+    if (l31 == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(carry + lhi * 128 + i * 16) = make_uint4(0, 0, 0, 0);
+    }
+    load_patch(0);
+    int buf = 0;
+#ifdef W2C_STEM_TIMING
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = clock64();
+#endif
+    for (int ox0 = 0; ox0 < Wo; ox0 += 32, buf ^= 1) {
+        uint2* patch = reinterpret_cast<uint2*>(smem + buf * FP_BYTES);
+        store_patch(patch);
+        STEM_T(0);
+        __syncthreads();                    // patch(step) visible; the buffer step+1 will overwrite was last read in step-1
+        STEM_T(1);
+        if (ox0 + 32 < Wo) load_patch(ox0 + 32);
+        STEM_T(2);
+
+        // ---- 9 conv rows x 32 columns x this wave's 32 channels, in two passes (rows 0-4, then 5-8) so that the live
+        // accumulators (80 + 64 registers instead of 144) leave room for two waves per SIMD; BN + ReLU, then the vertical
+        // 3-max in registers: pooled row p <- conv rows 2p, 2p+1, 2p+2 (row 0 = oy0-1); row 4 feeds both passes and is
+        // kept as 16 post-ReLU values.  acc element e = channel (e&3) + 8(e>>2) + 4 lhi; packed dword d of pooled row p
+        // holds the channels of e = 2d, 2d+1. ----
+        // horizontal 3-max of two pooled rows (lane = conv column; even lanes 2j end up with pooled column j), then those
+        // rows' pooled pixels -> wave-private staging [pooled row][pooled col][32 ch] -> 16-B stores
+        auto finish_rows = [&](int pr0, uint32_t (&pk2)[2][8]) {
+            uint4 cin[4];
+            if (l31 == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cin[i] = *reinterpret_cast<const uint4*>(carry + lhi * 128 + pr0 * 32 + i * 16);
+            }
+            asm volatile("" ::: "memory");                     // the carry is read before this step overwrites it
+            if (l31 == 31) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    *reinterpret_cast<uint4*>(carry + lhi * 128 + (pr0 + pr) * 32) = make_uint4(pk2[pr][0], pk2[pr][1], pk2[pr][2], pk2[pr][3]);
+                    *reinterpret_cast<uint4*>(carry + lhi * 128 + (pr0 + pr) * 32 + 16) = make_uint4(pk2[pr][4], pk2[pr][5], pk2[pr][6], pk2[pr][7]);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    uint32_t left = lane_from_left(pk2[pr][d]);
+                    if (l31 == 0) {
+                        const uint4 c = cin[pr * 2 + (d >> 2)];
+                        left = (d & 3) == 0 ? c.x : (d & 3) == 1 ? c.y : (d & 3) == 2 ? c.z : c.w;
+                    }
+                    const uint32_t right = lane_from_right(pk2[pr][d]);
+                    pk2[pr][d] = pk_max_u16(pk_max_u16(left, pk2[pr][d]), right);
+                }
+            }
+            if ((l31 & 1) == 0) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)    // channels 8q + 4 lhi .. +4  -> bytes (8q + 4 lhi) * 2
+                        *reinterpret_cast<uint2*>(stgw + ((pr0 + pr) * 16 + (l31 >> 1)) * 64 + (8 * q + 4 * lhi) * 2) =
+                            make_uint2(pk2[pr][2 * q], pk2[pr][2 * q + 1]);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {       // a pooled row: 16 pixels x 64 B = 64 lanes x 16 B
+                const uint4 o = *reinterpret_cast<const uint4*>(stgw + (pr0 + pr) * 1024 + lane * 16);
+                const int py = (oy0 >> 1) + pr0 + pr, px = (ox0 >> 1) + (lane >> 2);
+                *reinterpret_cast<uint4*>(y + (((size_t)img * Hp + py) * Wp + px) * COUT + ct * 32 + (lane & 3) * 8) = o;
+            }
+        };
+        float keep[16];
+        auto conv_rows = [&](auto first_tag, auto count_tag, f32x16_t* acc) {
+            constexpr int R0 = decltype(first_tag)::value, RN = decltype(count_tag)::value;
+#pragma unroll
+            for (int m = 0; m < RN; ++m) {
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    const uint2* prow = patch + (2 * (R0 + m) + ky) * FP_COLS + 2 * l31 + 2 * lhi;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(prow + ks * 4);
+                        if (ky == 0 && ks == 0)                 // zero C operand: no accumulator zeroing (144 v_mov per step)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], pb, f32x16_t{0.f}, 0, 0, 0);
+                        else
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], pb, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        constexpr float NEG_INF = -3.0e38f;
+        {
+            uint32_t pk[2][8];
+            f32x16_t acc[5];
+            conv_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, acc);
+            STEM_T(3);
+            const bool in0 = oy0 > 0;                          // conv row oy0-1 is outside the image for the first band
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(ssw + q * 32), sh = *reinterpret_cast<const f32x4_t*>(ssw + 128 + q * 32);
+                float v0[4], v1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * q + k;
+                    keep[e] = acc[4][e];
+                    const float m0 = fmaxf(fmaxf(in0 ? acc[0][e] : NEG_INF, acc[1][e]), acc[2][e]);
+                    const float m1 = fmaxf(fmaxf(acc[2][e], acc[3][e]), acc[4][e]);
+                    v0[k] = fmaxf(m0 * sc[k] + sh[k], 0.f);
+                    v1[k] = fmaxf(m1 * sc[k] + sh[k], 0.f);
+                }
+                pk[0][2 * q] = pack_bf16x2(v0[0], v0[1]) & 0x7FFF7FFFu;       // sign cleared: u16 ordering below
+                pk[0][2 * q + 1] = pack_bf16x2(v0[2], v0[3]) & 0x7FFF7FFFu;
+                pk[1][2 * q] = pack_bf16x2(v1[0], v1[1]) & 0x7FFF7FFFu;
+                pk[1][2 * q + 1] = pack_bf16x2(v1[2], v1[3]) & 0x7FFF7FFFu;
+            }
+            STEM_T(4);
+            finish_rows(0, pk);
+            STEM_T(5);
+        }
+        {
+            uint32_t pk[2][8];
+            f32x16_t acc[4];
+            conv_rows(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, acc);
+            STEM_T(6);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(ssw + q * 32), sh = *reinterpret_cast<const f32x4_t*>(ssw + 128 + q * 32);
+                float v2[4], v3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * q + k;
+                    const float m2 = fmaxf(fmaxf(keep[e], acc[0][e]), acc[1][e]);
+                    const float m3 = fmaxf(fmaxf(acc[1][e], acc[2][e]), acc[3][e]);
+                    v2[k] = fmaxf(m2 * sc[k] + sh[k], 0.f);
+                    v3[k] = fmaxf(m3 * sc[k] + sh[k], 0.f);
+                }
+                pk[0][2 * q] = pack_bf16x2(v2[0], v2[1]) & 0x7FFF7FFFu;
+                pk[0][2 * q + 1] = pack_bf16x2(v2[2], v2[3]) & 0x7FFF7FFFu;
+                pk[1][2 * q] = pack_bf16x2(v3[0], v3[1]) & 0x7FFF7FFFu;
+                pk[1][2 * q + 1] = pack_bf16x2(v3[2], v3[3]) & 0x7FFF7FFFu;
+            }
+            finish_rows(2, pk);
+        }
+        asm volatile("" ::: "memory");             // next step's staging writes stay behind these reads (same wave: in order)
+        STEM_T(7);
+    }
+#ifdef W2C_STEM_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stem_phase[i], t_acc[i]);
+#endif
+}
+
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, int M, int H, int W, int C,
                                                            uint16_t* __restrict__ y) {
     const int Ho = H >> 1, Wo = W >> 1, CG = C >> 3;
@@ -458,12 +731,27 @@ static int launch_stem_pool_band(const void* x, FrameMean mean, int B, int N, in
 }
 
 template <int COUT, bool U8>
+static int launch_stem_pool2(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+                             const float* shift, uint16_t* y, hipStream_t s) {
+    constexpr int lds = 2 * fp_bytes<8>() + (COUT / 32) * (4096 + 256 + 256);
+    dim3 grid((H / 2) / 8, N * B);
+    hipLaunchKernelGGL((stem_pool2_kernel<COUT, U8>), grid, dim3(COUT * 2), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
+    return w2c_launch_status();
+}
+
+template <int COUT, bool U8>
 static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                             const float* shift, uint16_t* y, hipStream_t s) {
     static const int band = [] { const char* e = getenv("W2C_STEM_BAND"); return e ? atoi(e) : 8; }();
     // measured (tools/bench_stem.py, cfg 2): BAND 8 143 us, BAND 4 154 us -- the second resident workgroup does not pay
     // for its 5/4 recompute; W2C_STEM_BAND=4 keeps the A/B reproducible.
     // 12 waves (conv rows split 3/3/3 instead of 4/5): measured 159 us vs 145 us for 8 waves -- kept for the A/B only
+    // Cout = 128 (both trunks side by side): the register-pooling form (measured 110 us vs 141 us at cfg 2; ablations: MFMA +
+    // fragment reads 54 us, BN/max/pack/staging VALU 53 us, patch I/O 15 us -- still serial inside a wave, two waves per
+    // SIMD overlap 1.5x).  Cout = 64 (Single_agent): the LDS-pooling form is faster (95 vs 104 us).  W2C_STEM_FORM=1|2 forces.
+    static const int form = [] { const char* e = getenv("W2C_STEM_FORM"); return e ? atoi(e) : 0; }();
+    if ((form == 2 || (form == 0 && COUT == 128)) && H % 16 == 0)
+        return launch_stem_pool2<COUT, U8>(x, mean, B, N, H, W, w, scale, shift, y, s);
     static const int nw = [] { const char* e = getenv("W2C_STEM_WAVES"); return e ? atoi(e) : 8; }();
     if (band == 4) return launch_stem_pool_band<COUT, U8, 4, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);
     if (nw == 12 && COUT == 128) return launch_stem_pool_band<COUT, U8, 8, (COUT == 128 ? 12 : 8)>(x, mean, B, N, H, W, w, scale, shift, y, s);

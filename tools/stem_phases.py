@@ -42,6 +42,9 @@ def main():
     lib.w2c_debug_stem_phases(buf, 0)
     steps = reps * (S // 2 // 8) * (N * B) * (S // 2 // 32)
     names = ["store_patch", "barrier A", "issue loads", "MFMA loop", "BN+stage", "barrier B", "pool+store", "barrier C+carry"]
+    if os.environ.get("W2C_STEM_FORM") == "2":
+        names = ["store_patch", "barrier", "issue loads", "MFMA rows 0-4", "BN+vmax+pack A", "hmax+stage+store A", "MFMA rows 5-8",
+                 "BN..store B"]
     tot = 0
     for n, v in zip(names, buf):
         print("%-16s %8.0f cycles / workgroup-step" % (n, v / steps))
