@@ -749,6 +749,8 @@ static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, 
     // Cout = 128 (both trunks side by side): the register-pooling form (measured 110 us vs 141 us at cfg 2; ablations: MFMA +
     // fragment reads 54 us, BN/max/pack/staging VALU 53 us, patch I/O 15 us -- still serial inside a wave, two waves per
     // SIMD overlap 1.5x).  Cout = 64 (Single_agent): the LDS-pooling form is faster (95 vs 104 us).  W2C_STEM_FORM=1|2 forces.
+    // Measured and dropped: a 3-waves/SIMD build (4 accumulation passes, 168 registers: 40 spilled dwords -> 186 us), 4-row
+    // bands for a finer tail (1280 half-size workgroups: 112 us), staggered starts of co-resident workgroups (no change).
     static const int form = [] { const char* e = getenv("W2C_STEM_FORM"); return e ? atoi(e) : 0; }();
     if ((form == 2 || (form == 0 && COUT == 128)) && H % 16 == 0)
         return launch_stem_pool2<COUT, U8>(x, mean, B, N, H, W, w, scale, shift, y, s);
