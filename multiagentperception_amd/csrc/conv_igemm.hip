@@ -812,7 +812,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
                          : (m_inval | (yn == 0 ? m_top : 0u) | (yn + 4 == p.H ? m_bot : 0u) | (xn == 0 ? m_left : 0u) |
                             (xn + 16 == p.W ? m_right : 0u));
         }
-        if (t == t_begin) wait_vmcnt<0>();         // later tiles: patch(t) was waited for before epilogue(t-1)
+        // patch(t) must have landed.  First tile: everything issued so far.  Later tiles: its 14 pieces were issued during
+        // tile t-1 and are older than that tile's output stores (8, or 16 for f32 output), which may stay in flight --
+        // vmcnt retires in issue order on gfx9 (the compiler's own waitcnt insertion relies on the same).
+        if (t == t_begin) wait_vmcnt<0>();
+        else if (p.y_f32) wait_vmcnt<16>();
+        else wait_vmcnt<8>();
         asm volatile("" ::: "memory");
         stamp(0);
 
@@ -877,9 +882,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
                 for (int eg = 0; eg < 4; ++eg)
                     *reinterpret_cast<f32x4_t*>(stage + l31 * SPITCH + (ct * 32 + eg * 8 + lhi * 4) * 4) =
                         f32x4_t{acc[pt][ct][eg * 4], acc[pt][ct][eg * 4 + 1], acc[pt][ct][eg * 4 + 2], acc[pt][ct][eg * 4 + 3]};
-            if (pt == 0) {     // residual(t) and patch(t+1) were issued 14+ K-steps ago; this also retires the stores of tile t-1
-                asm volatile("" ::: "memory");
-                wait_vmcnt<0>();
+            if (pt == 0) {     // residual(t) (issued at K-steps 1-8) must have landed; the 14 younger pieces of patch(t+1) may
+                asm volatile("" ::: "memory");      // still be in flight (HBM latency > the 14 K-steps since their issue)
+                if (HAS_RES) wait_vmcnt<14>();
                 asm volatile("" ::: "memory");
                 stamp(2);
             }
