@@ -138,6 +138,13 @@ int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M, int K,
  * out : f32 [M, O].  H1 <= 256. */
 int w2c_head_tail_f32(const float* h0, int h0_stride, int M, int K1, const float* w1t, const float* b1, int H1,
                       const float* w2t, const float* b2, int O, float* out, w2c_stream_t stream);
+/* Both heads' tails in one launch (key_net and query_net read disjoint column ranges [col_off, col_off+K1) of the same
+ * fc.0 output h0; agent.py:1126-1129): out_x[M, O_x] = W2_x relu(W1_x h0[:, col_off_x : col_off_x+K1] + b1_x) + b2_x. */
+int w2c_head_tail2_f32(const float* h0, int h0_stride, int M, int K1, int H1,
+                       int col_off_a, const float* w1t_a, const float* b1_a, const float* w2t_a, const float* b2_a, int O_a, float* out_a,
+                       int col_off_b, const float* w1t_b, const float* b1_b, const float* w2t_b, const float* b2_b, int O_b, float* out_b,
+                       w2c_stream_t stream);
+
 
 /* ---- K6: communication graph.  MIMOGeneralDotProductAttention scores +
  * softmax over keys (agent.py:256,268,274), the +0.001*I tie-break

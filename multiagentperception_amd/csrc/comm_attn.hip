@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restric
 // K-MAJOR ([K][O]) so consecutive threads read consecutive outputs of one k (coalesced, L2-resident).
 // Latency-bound by construction (tiny), so every loop keeps 16 independent loads in flight; each slice
 // recomputes the 128-wide hidden layer (32 K MACs) rather than synchronising through memory.
-__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ h0, int h0_stride, int K1,
-                                                        const float* __restrict__ w1t, const float* __restrict__ b1, int H1,
-                                                        const float* __restrict__ w2t, const float* __restrict__ b2, int O,
-                                                        float* __restrict__ out) {
+__device__ __forceinline__ void head_tail_body(const float* __restrict__ h0, int h0_stride, int K1,
+                                               const float* __restrict__ w1t, const float* __restrict__ b1, int H1,
+                                               const float* __restrict__ w2t, const float* __restrict__ b2, int O,
+                                               float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_h0 = reinterpret_cast<float*>(smem);          // [K1]
     float* s_h1 = s_h0 + K1;                               // [H1]
@@ -186,6 +186,22 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         for (; k < H1; ++k) a[0] = fmaf(w2t[(size_t)k * O + o], s_h1[k], a[0]);
         out[(size_t)m * O + o] = (a[0] + a[1]) + (a[2] + a[3]) + b2[o];
     }
+}
+
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ h0, int h0_stride, int K1,
+                                                        const float* __restrict__ w1t, const float* __restrict__ b1, int H1,
+                                                        const float* __restrict__ w2t, const float* __restrict__ b2, int O,
+                                                        float* __restrict__ out) {
+    head_tail_body(h0, h0_stride, K1, w1t, b1, H1, w2t, b2, O, out);
+}
+
+// both heads (key and query tails read disjoint column ranges of the same fc.0 output) in ONE launch: blockIdx.z = head.
+struct HeadTailSet { const float* w1t; const float* b1; const float* w2t; const float* b2; float* out; int col_off; int O; };
+__global__ __launch_bounds__(256) void head_tail2_kernel(const float* __restrict__ h0, int h0_stride, int K1, int H1,
+                                                         HeadTailSet a, HeadTailSet b) {
+    const HeadTailSet& s = blockIdx.z == 0 ? a : b;
+    if ((int)blockIdx.y * 256 >= s.O) return;              // the narrower head has fewer 256-output slices (whole workgroup)
+    head_tail_body(h0 + s.col_off, h0_stride, K1, s.w1t, s.b1, H1, s.w2t, s.b2, s.O, s.out);
 }
 
 // ---------------------------------------------------------------- K6: communication graph
@@ -380,6 +396,23 @@ extern "C" int w2c_head_tail_f32(const float* h0, int h0_stride, int M, int K1, 
     const size_t lds = (size_t)(K1 + H1 + 256) * 4;
     hipLaunchKernelGGL(head_tail_kernel, dim3(M, (O + 255) / 256), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        h0, h0_stride, K1, w1t, b1, H1, w2t, b2, O, out);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_head_tail2_f32(const float* h0, int h0_stride, int M, int K1, int H1,
+                                  int col_off_a, const float* w1t_a, const float* b1_a, const float* w2t_a, const float* b2_a, int O_a,
+                                  float* out_a,
+                                  int col_off_b, const float* w1t_b, const float* b1_b, const float* w2t_b, const float* b2_b, int O_b,
+                                  float* out_b, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!h0 || !w1t_a || !b1_a || !w2t_a || !b2_a || !out_a || !w1t_b || !b1_b || !w2t_b || !b2_b || !out_b) return W2C_E_ARG;
+    if (M <= 0 || K1 <= 0 || H1 <= 0 || H1 > 256 || O_a <= 0 || O_b <= 0 || col_off_a < 0 || col_off_b < 0) return W2C_E_ARG;
+    if (h0_stride < col_off_a + K1 || h0_stride < col_off_b + K1) return W2C_E_ARG;
+    const size_t lds = (size_t)(K1 + H1 + 256) * 4;
+    const int omax = O_a > O_b ? O_a : O_b;
+    HeadTailSet a{w1t_a, b1_a, w2t_a, b2_a, out_a, col_off_a, O_a}, b{w1t_b, b1_b, w2t_b, b2_b, out_b, col_off_b, O_b};
+    hipLaunchKernelGGL(head_tail2_kernel, dim3(M, (omax + 255) / 256, 2), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       h0, h0_stride, K1, H1, a, b);
     return w2c_launch_status();
 }
 

@@ -169,6 +169,9 @@ class HeadPlan:
     def run(self, qk_map):
         M = qk_map.shape[0]
         h0 = ops.linear(qk_map, self.w0, self.b0, relu=True, x_stride=self.n_feat, rows=M)     # [M, 256*nheads]
+        if len(self.tails) == 2 and self.tails[0][0] == self.tails[1][0]:      # key + query heads: one launch
+            (k1, wa1, ba1, wa2, ba2), (_, wb1, bb1, wb2, bb2) = self.tails
+            return list(ops.head_tail2(h0, k1, (0, wa1, ba1, wa2, ba2), (k1, wb1, bb1, wb2, bb2)))
         outs, col = [], 0
         for k1, w1t, b1, w2t, b2 in self.tails:
             outs.append(ops.head_tail(h0, col, k1, w1t, b1, w2t, b2))

@@ -237,6 +237,24 @@ def head_tail(h0, col_off, k1, w1t, b1, w2t, b2):
     return out
 
 
+def head_tail2(h0, k1, tail_a, tail_b):
+    """Both heads' tails in one launch: tail_x = (col_off, w1t, b1, w2t, b2) -> (out_a [M,O_a], out_b [M,O_b])."""
+    ca, w1a, b1a, w2a, b2a = tail_a
+    cb, w1b, b1b, w2b, b2b = tail_b
+    dev = _need_gpu(h0, w1a, b1a, w2a, b2a, w1b, b1b, w2b, b2b)
+    M, stride = h0.shape
+    H1 = w1a.shape[1]
+    if w1b.shape[1] != H1:
+        raise W2CError("head_tail2: both heads must share the hidden width")
+    out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
+    out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_head_tail2_f32(_p(h0), stride, M, k1, H1, ca, _p(w1a), _p(b1a), _p(w2a), _p(b2a), w2a.shape[1],
+                                               _p(out_a), cb, _p(w1b), _p(b1b), _p(w2b), _p(b2b), w2b.shape[1], _p(out_b),
+                                               _stream(dev)), "w2c_head_tail2_f32")
+    return out_a, out_b
+
+
 MODE_IDS = {"softmax": 0, "argmax_test": 1, "activated": 2}
 
 

@@ -485,6 +485,21 @@ def test_u8_frame_stem_equals_f32_stem_on_transformed_frames(cout, B, N, H, W):
     assert torch.equal(got, ref)
 
 
+def test_head_tail2_equals_two_single_head_launches():
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(77)
+    M, K1, H1 = 20, 256, 128
+    h0 = torch.randn(M, 2 * K1, generator=gen).to(_dev())
+    mk = lambda *sh: (torch.randn(*sh, generator=gen) * 0.1).to(_dev())
+    ta = (0, mk(K1, H1), mk(H1), mk(H1, 33), mk(33))
+    tb = (K1, mk(K1, H1), mk(H1), mk(H1, 1024), mk(1024))          # second head wider than one 256-output slice
+    a, b = ops.head_tail2(h0, K1, ta, tb)
+    ra = ops.head_tail(h0, ta[0], K1, *ta[1:])
+    rb = ops.head_tail(h0, tb[0], K1, *tb[1:])
+    torch.cuda.synchronize()
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+
+
 def test_bad_arguments_raise_not_abort():
     from multiagentperception_amd import ops
     from multiagentperception_amd._native import W2CError
