@@ -285,6 +285,31 @@ def test_fused_stem_maxpool_equals_unfused_bit_for_bit(cout, B, N, H, W):
     assert torch.equal(got, ref)
 
 
+def test_fused_stem_is_deterministic_under_full_occupancy():
+    """Both fused-stem forms at the cfg-2 shape (640 workgroups, 2 per CU for the register-pooling form: wave-private LDS
+    regions, one barrier per step): 15 launches bit-identical, and the two forms equal each other."""
+    import os
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    B, N, S, cout = 4, 5, 512, 128
+    x = (torch.rand(B, 3 * N, S, S, generator=gen) - 0.45).to(_dev())
+    wp = torch.zeros(cout, 7, 8, 4)
+    wp[:, :, :7, :3] = torch.randn(cout, 7, 7, 3, generator=gen) * (2.0 / 147) ** 0.5
+    w = wp.reshape(cout, 224).to(BF16).to(_dev())
+    scale = torch.rand(cout, generator=gen) + 0.5
+    scale[1::4] = -scale[1::4]
+    scale = scale.to(_dev())
+    shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
+    first = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift).clone()
+    for _ in range(15):
+        y = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift)
+        torch.cuda.synchronize()
+        assert torch.equal(y, first)
+    ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
+    torch.cuda.synchronize()
+    assert torch.equal(first, ref)
+
+
 def test_maxpool_is_exact():
     from multiagentperception_amd import ops
     gen = torch.Generator().manual_seed(5)

@@ -1,5 +1,6 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multiagentperception_amd import ops
 BF16 = torch.bfloat16
 dev = torch.device('cuda:0')
@@ -19,8 +20,8 @@ def run(name, M,H,W,cin,cout,G,ref_v,variants,reps=60,stride=1,ks=3):
             if not torch.equal(y, first): bad+=1
         d = float((first.float()-ref.float()).abs().max())
         print("%-26s v%-3d: %d/%d runs differ from the first run; max|first-ref(v%d)| %.4f"%(name,v,bad,reps,ref_v,d))
-run("l1 64->64 @128 g2", 20,128,128,64,64,2, 3, [3,31,34,36,38,39])
-run("l2 128->128 @64 g2", 20,64,64,128,128,2, 0, [0,30,31,26,35,37,36])
+run("l1 64->64 @128 g2", 20,128,128,64,64,2, 3, [3,31,34,36,38,39,50])
+run("l2 128->128 @64 g2", 20,64,64,128,128,2, 0, [0,30,31,26,35,37,36,51])
 run("l3 256->256 @32 g2", 20,32,32,256,256,2, 0, [0,30,33])
 run("l4 512->512 @16 g2", 20,16,16,512,512,2, 0, [3,30,26])
 run("pol2 512->256 @16", 20,16,16,512,256,1, 6, [6,31])
