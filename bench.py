@@ -109,7 +109,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from oracle import filler                     # weights/inputs generator shared with the parity fixtures
+    from multiagentperception_amd import synth as filler     # deterministic weights / synthetic frames (same generator as the fixtures)
     from ptsemseg.models import get_model          # the reference's import path
     from multiagentperception_amd import ops
     from multiagentperception_amd.parallel import AgentParallelForward

@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): stage-by-stage error of the HIP path vs the fp32 oracle, next to a CPU
+"""TEST INFRASTRUCTURE.  Diagnostic (not a test): stage-by-stage error of the HIP path vs the fp32 oracle, next to a CPU
 emulation of bf16 storage rounding (what ANY bf16 pipeline would lose on these weights)."""
 import os
 import sys

@@ -31,8 +31,7 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
 from oracle import filler  # noqa: E402
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-import diag_forward as diag  # noqa: E402
+from oracle import diag_forward as diag  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 MARGIN = 0.04
@@ -185,7 +184,7 @@ def run_case(ref_models, ref_metrics, name, arch, yml, agent_num, batch, size, m
             top2 = p_try.topk(2, dim=1)[0]
             if float((p_try - 0.2).abs().min()) >= MARGIN and float((top2[:, 0] - top2[:, 1]).min()) >= MARGIN:
                 # also require the fixture to be well conditioned for ANY bf16-storage pipeline: the
-                # oracle with conv operands / ReLU outputs rounded to bf16 (tools/diag_forward.py) must
+                # oracle with conv operands / ReLU outputs rounded to bf16 (oracle/diag_forward.py) must
                 # itself stay well inside the stated GPU tolerances.
                 from oracle import when2com_oracle as orc
                 sd = orc.to_torch(filler.fill_state_dict(orc.state_spec(arch, image_size=size, has_query=hasattr(model, "query_net"))))

@@ -19,8 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import filler, make_golden as mg  # noqa: E402
 from oracle import when2com_oracle as orc  # noqa: E402
-sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
-import diag_forward as diag  # noqa: E402
+from oracle import diag_forward as diag  # noqa: E402
 
 GOLD = mg.GOLD
 MARGIN = 0.04

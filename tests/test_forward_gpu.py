@@ -9,7 +9,7 @@ which measured the reference against its OWN bf16 autocast at rel-L2 4.6e-3, arg
       UN-renormalised P*(P>0.2) (agent.py:1060-1062), so the bf16 error of P (below) multiplies the fused
       feature map directly: dP/P ~ 1.25e-2/0.6 = 2 % measured on the 6-agent fixture.
   prob_action: atol 2e-2.  Derivation: the policy trunk stores bf16 activations, so keys carry
-      ~6e-3 relative error (measured: HIP 6.4e-3, CPU bf16-storage emulation 6.7e-3, tools/diag_forward.py);
+      ~6e-3 relative error (measured: HIP 6.4e-3, CPU bf16-storage emulation 6.7e-3, oracle/diag_forward.py);
       delta_score ~ 6e-3*|score| with |score| up to ~8.5 on these fixtures, and |dP| <= P(1-P)*delta_score
       <= 0.25*0.07 ~ 1.7e-2.  (An fp32 score path cannot help: the error is already in the keys.)
   action: exact wherever the oracle's top-2 margin > 0.04 (fixtures are chosen with margin >= 0.04)
@@ -241,9 +241,7 @@ def test_hip_graph_replay_equals_eager_bit_for_bit():
 def test_baseline_config_shapes_match_oracle(arch, n, b, size, mode):
     """The other BASELINE.json configs' shapes on one GPU vs the fp32 oracle (no golden vectors at these sizes:
     the oracle itself is pinned by the 128^2 / 256^2 reference vectors)."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import diag_forward as diag
+    from oracle import diag_forward as diag
     has_query = arch != "MIMOcomWho"
     case = dict(arch=arch, agent_num=n, batch=b, size=size, model_over={} if has_query else {})
     model, _ = _build(case)
