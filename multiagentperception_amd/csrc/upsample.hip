@@ -78,24 +78,32 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
         const int y0 = (int)sy;
         const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
         const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-        uint32_t packed = 0;
+        // the 4 pixels of a group share their source columns: x0 changes only at ox = 16 (mod 32), a multiple of 4, and the
+        // left-edge clamp (sx < 0 -> 0) covers ox < 16 -- so the four corner values are read once per class, not per pixel
+        float sx0 = (gx * 4 + 0.5f) * 0.03125f - 0.5f;
+        sx0 = sx0 < 0.f ? 0.f : sx0;
+        const int x0 = (int)sx0;
+        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        float lx1[4], lx0[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int ox = gx * 4 + e;
-            float sx = (ox + 0.5f) * 0.03125f - 0.5f;
+            float sx = (gx * 4 + e + 0.5f) * 0.03125f - 0.5f;
             sx = sx < 0.f ? 0.f : sx;
-            const int x0 = (int)sx;
-            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-            float best = -INFINITY;
-            int bi = 0;
-            for (int c = 0; c < ncls; ++c) {
-                const float* pl = blk + c * h * w;
-                const float v = lerp2d(ly0, ly1, lx0, lx1, pl[y0 * w + x0], pl[y0 * w + x1], pl[y1 * w + x0], pl[y1 * w + x1]);
-                if (v > best) { best = v; bi = c; }
-            }
-            packed |= (uint32_t)bi << (8 * e);
+            lx1[e] = sx - (float)x0;
+            lx0[e] = 1.f - lx1[e];
         }
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int c = 0; c < ncls; ++c) {
+            const float* pl = blk + c * h * w;
+            const float p00 = pl[y0 * w + x0], p01 = pl[y0 * w + x1], p10 = pl[y1 * w + x0], p11 = pl[y1 * w + x1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = lerp2d(ly0, ly1, lx0[e], lx1[e], p00, p01, p10, p11);
+                if (v > best[e]) { best[e] = v; bi[e] = c; }
+            }
+        }
+        const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
         *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W + gx * 4) = packed;
     }
 }
