@@ -193,13 +193,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int lswz = swz(l31);             // tile / wave offsets are multiples of 32: swz(row) == swz(l31)
-    // epilogue constants fetched now: their latency hides under the main loop
-    float e_sc[NI], e_sh[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        e_sc[j] = p.scale[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
-        e_sh[j] = p.shift[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
-    }
+    // epilogue constants fetched now (their latency hides under the main loop): BN scale / shift of the 8 channels this
+    // thread writes out (read-out item = (tile row, 8-channel group cg = tid % (BN/8)), the same cg in every pass)
+    const float* ssp = p.scale + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+    const float* shp = p.shift + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+    const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssp), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssp + 4);
+    const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
 
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE_BYTES;
@@ -221,7 +220,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+                    // A = weights, B = pixels: D[channel][pixel] -- four consecutive channels of a pixel per accumulator quad
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
     };
 
     // ---- main loop: STAGES-deep ring, counted waits, one barrier per K-step ----
@@ -272,17 +272,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     // ---- epilogue 1: scale/shift in registers, tile -> LDS as f32 [BM][CLD] ----
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int nl = wn * WTN + j * 32 + l31;
-        const float sc = SPLITK ? 1.f : e_sc[j], sh = SPLITK ? 0.f : e_sh[j];   // split-K: raw partial sums
+    for (int i = 0; i < MI; ++i) {
+        const int ml = wm * WTM + i * 32 + l31;                   // D column = pixel (tile row)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;   // C/D row map of 32x32 MFMA
-                Cs[ml * CLD + nl] = SPLITK ? acc[i][j][e] : acc[i][j][e] * sc + sh;
-            }
-        }
+            for (int eg = 0; eg < 4; ++eg)                        // D rows 8 eg + 4 lhi .. +4 = four consecutive channels
+                *reinterpret_cast<f32x4_t*>(Cs + ml * CLD + wn * WTN + j * 32 + eg * 8 + lhi * 4) =
+                    f32x4_t{acc[i][j][eg * 4], acc[i][j][eg * 4 + 1], acc[i][j][eg * 4 + 2], acc[i][j][eg * 4 + 3]};
     }
     __syncthreads();
 
@@ -307,8 +304,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * NT + tid;
         const int r = idx / CG, cg = idx - r * CG;
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4);
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8) * e_sc0 + e_sh0;
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4) * e_sc1 + e_sh1;
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const uint32_t rw[4] = {e_res[ps].x, e_res[ps].y, e_res[ps].z, e_res[ps].w};
 #pragma unroll
@@ -466,12 +463,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         pp0[i] = (tp / TW) * PW + (tp % TW);
     }
     const int bswz = (l31 >> 1) & 7;
-    float e_sc[NI], e_sh[NI];                                   // epilogue constants: latency hidden by the main loop
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        e_sc[j] = p.scale[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
-        e_sh[j] = p.shift[g * p.Cout + n0 + wn * WTN + j * 32 + l31];
-    }
+    // epilogue constants (latency hidden by the main loop): BN scale / shift of the 8 channels this thread writes out
+    // (read-out item = (tile row, 8-channel group cg = tid % (BN/8)), the same cg in every pass)
+    const float* ssp = p.scale + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+    const float* shp = p.shift + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+    const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssp), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssp + 4);
+    const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
 
     bf16x8_t fa[4][MI], fb[4][NI];                              // fragment registers of ONE K-step (tap)
     auto load_frags = [&](const char* patch, const char* Bs, int dk) {
@@ -501,7 +498,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                    // A = weights, B = pixels: D[channel][pixel], so a lane holds 4 CONSECUTIVE CHANNELS of one pixel per
+                    // accumulator quad and the epilogue stages them with one ds_write_b128 instead of four ds_write_b32
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
     };
     using KS2 = std::integral_constant<int, STAGES - 2>;
 
@@ -597,24 +596,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     }
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int nl = wn * WTN + j * 32 + l31;
-        const float sc = e_sc[j], sh = e_sh[j];
+    for (int i = 0; i < MI; ++i) {
+        const int ml = wm * WTM + i * 32 + l31;                   // D column = pixel
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                Cs[ml * CLD + nl] = acc[i][j][e] * sc + sh;
-            }
+            for (int eg = 0; eg < 4; ++eg)                        // D rows 8 eg + 4 lhi .. +4 = four consecutive channels
+                *reinterpret_cast<f32x4_t*>(Cs + ml * CLD + wn * WTN + j * 32 + eg * 8 + lhi * 4) =
+                    f32x4_t{acc[i][j][eg * 4], acc[i][j][eg * 4 + 1], acc[i][j][eg * 4 + 2], acc[i][j][eg * 4 + 3]};
     }
     __syncthreads();
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * NT + tid;
         const int r = idx / CG, cg = idx - r * CG;
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4);
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8) * e_sc0 + e_sh0;
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4) * e_sc1 + e_sh1;
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const uint32_t rw[4] = {e_res[ps].x, e_res[ps].y, e_res[ps].z, e_res[ps].w};
 #pragma unroll
