@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #pragma unroll
     for (int j = 0; j < P_INSTR; ++j) {
         const int q = (wave + NW * j) * 8 + lrow;                    // patch pixel index
-        const int chunk = lpos ^ ((q >> 1) & 7);
         const int py = q / PW, px = q - py * PW;
+        const int chunk = lpos ^ ((px >> 1) & 7);                    // swizzle keyed on the patch COLUMN (see load_frags)
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
         pa_off[j] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8) * 2) : 0x80000000u;
@@ -456,11 +456,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    int pp0[MI];                                                // patch pixel of this lane's row at tap (0,0)
+    int pp0[MI], pc0[MI];                                       // patch pixel / patch column of this lane's row at tap (0,0)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int tp = wm * WTM + i * 32 + l31;
-        pp0[i] = (tp / TW) * PW + (tp % TW);
+        pc0[i] = tp % TW;
+        pp0[i] = (tp / TW) * PW + pc0[i];
     }
     const int bswz = (l31 >> 1) & 7;
     // epilogue constants (latency hidden by the main loop): BN scale / shift of the 8 channels this thread writes out
@@ -471,14 +472,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
 
     bf16x8_t fa[4][MI], fb[4][NI];                              // fragment registers of ONE K-step (tap)
-    auto load_frags = [&](const char* patch, const char* Bs, int dk) {
+    // LDS slot of chunk c of patch pixel (row, col): c ^ ((col >> 1) & 7), at byte (row*PW + col)*128.  Keyed on the COLUMN:
+    // a wave's 32 pixels lie on two patch rows when TW = 16, and ds_read_b128 services lanes {0-3,12-15,20-27} (etc.)
+    // together -- columns {c..c+3, c+12..c+15} of one row and {c+4..c+11} of the next, a complete residue system mod 16 =>
+    // 16 distinct 16-B slots of the 256-B bank row.  (Keyed on the linear pixel index the two rows collide: PMC showed
+    // 33 % of the LDS cycles of these kernels were bank conflicts.)
+    auto load_frags = [&](const char* patch, const char* Bs, int dk, int kx) {
         const char* arow[MI];
         int aswz[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int pp = pp0[i] + dk;
             arow[i] = patch + pp * 128;
-            aswz[i] = (pp >> 1) & 7;
+            aswz[i] = ((pc0[i] + kx) >> 1) & 7;
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #endif
             if (t == 0) dbg_stamp(p, 1);
 #ifdef W2C_READS_FIRST     // measured: fragment reads ahead of the DMA issue is SLOWER (l2 v30 55 -> 66 us at equal clocks)
-            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3));
+            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3), tap % 3);
 #endif
             if (t + STAGES - 1 < KT) issue_b(wr);
             if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
             const long long c3 = clock64();
 #endif
 #ifndef W2C_READS_FIRST
-            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3));
+            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3), tap % 3);
 #endif
 #ifdef W2C_PHASE_TIMING
             asm volatile("" ::: "memory");
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
     if (t_begin >= t_end) return;
 
     // ---- DMA constants.  Patch instruction j moves pixels q = 8j + lane/8 (q = row*18 + col), lane%8 = LDS chunk
-    // position; the bank swizzle (chunk c of pixel q sits at c ^ ((q>>1)&7)) is applied to the SOURCE chunk. ----
+    // position; the bank swizzle (chunk c of a pixel in patch column x sits at c ^ ((x>>1)&7)) is applied to the SOURCE chunk. ----
     const size_t x_bytes = (size_t)p.M * p.H * p.W * p.xcs * 2;
     const size_t y_bytes = (size_t)p.M * p.H * p.W * p.ycs * (p.y_f32 ? 4 : 2);
     const size_t r_bytes = (size_t)p.M * p.H * p.W * p.ycs * 2;
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
     for (int j = 0; j < 14; ++j) {
         const int q = 8 * j + (lane >> 3);
         const int dy = (q * 3641) >> 16, dx = q - dy * PW;          // q / 18, q % 18 for q < 128
-        const int chunk = (lane & 7) ^ ((q >> 1) & 7);
+        const int chunk = (lane & 7) ^ ((dx >> 1) & 7);             // swizzle keyed on the patch COLUMN (conflict-free, see above)
         off_rel[j] = ((dy * p.W + dx) * p.xcs + chunk * 8) * 2;
         m_top |= (dy == 0 ? 1u : 0u) << j;
         m_bot |= (dy == 5 ? 1u : 0u) << j;
@@ -832,8 +838,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
         auto tap_setup = [&](int tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int q0 = qv0 + ky * PW + kx, q1 = qv1 + ky * PW + kx;
-            fb[0] = q0 * 128; fx[0] = ((lhi ^ (q0 >> 1)) & 7) << 4;
-            fb[1] = q1 * 128; fx[1] = ((lhi ^ (q1 >> 1)) & 7) << 4;
+            const int cs = ((((l31 & 15) + kx) >> 1) ^ lhi) & 7;      // column-keyed swizzle, both pixel tiles share the column
+            fb[0] = q0 * 128; fx[0] = cs << 4;
+            fb[1] = q1 * 128; fx[1] = cs << 4;
         };
         auto frag = [&](int kc, int pt) { return *reinterpret_cast<const u32x4_t*>(pc + fb[pt] + ((kc << 5) ^ fx[pt])); };
         u32x4_t bx[2][2];
@@ -982,7 +989,7 @@ int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
 //     publishes patch(t) and retires the buffer patch(t+1) is about to overwrite;
 //   * everything else is private to the wave: its residual slice (64 pixels x 64 B), its f32 staging (both pixel
 //     tiles at once, no reuse hazard), its stores;  144 MFMAs per tile and wave, 1 B-fragment read per MFMA.
-// LDS patch row = 256 B per pixel; 16-B chunk C of pixel q sits at slot C ^ (q & 15).
+// LDS patch row = 256 B per pixel; 16-B chunk C of the pixel in patch column c sits at slot C ^ (c & 15).
 template <bool HAS_RES>
 __global__ __launch_bounds__(256) void conv3x3_c128_regw_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1044,7 +1051,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_regw_kernel(ConvArgs p) {
     for (int k = 0; k < 7; ++k) {
         const int q = 4 * (wave + 4 * k) + (lane >> 4);
         const int dy = (q * 3641) >> 16, dx = q - dy * PW;
-        const int chunk = (lane & 15) ^ (q & 15);
+        const int chunk = (lane & 15) ^ (dx & 15);                  // keyed on the patch column (conflict-free two-row reads)
         off_rel[k] = ((dy * p.W + dx) * p.xcs + chunk * 8) * 2;
         m_top |= (dy == 0 ? 1u : 0u) << k;
         m_bot |= (dy == 5 ? 1u : 0u) << k;
@@ -1121,8 +1128,9 @@ __global__ __launch_bounds__(256) void conv3x3_c128_regw_kernel(ConvArgs p) {
         auto tap_setup = [&](int tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int q0 = qv0 + ky * PW + kx, q1 = qv1 + ky * PW + kx;
-            fb[0] = q0 * 256; fx[0] = ((lhi ^ q0) & 15) << 4;
-            fb[1] = q1 * 256; fx[1] = ((lhi ^ q1) & 15) << 4;
+            const int cs = ((((l31 & 15) + kx) ^ lhi) & 15) << 4;
+            fb[0] = q0 * 256; fx[0] = cs;
+            fb[1] = q1 * 256; fx[1] = cs;
         };
         auto frag = [&](int kc, int pt) { return *reinterpret_cast<const u32x4_t*>(pc + fb[pt] + ((kc << 5) ^ fx[pt])); };
         u32x4_t bx[2][2];
