@@ -395,7 +395,10 @@ __global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) v
     constexpr int BAND = 8, CR = 9;
     constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>();
     constexpr int CT = COUT / 32, NT = 64 * CT;
-    constexpr int WAVE_LDS = 4096 + 256 + 256;                 // pooled staging [64 px][64 B] + carry [2 halves][128 B] + scale|shift
+    constexpr int SPX = 80;                                    // staging pitch per pooled pixel: 64 B + 16 (pixel rows 20 banks apart:
+                                                               // the 8 active lanes of a ds_write_b64 group hit distinct banks; at 64 B
+                                                               // they hit two -- PMC: 28 % of this kernel's LDS cycles were conflicts)
+    constexpr int WAVE_LDS = 64 * SPX + 256 + 256;             // pooled staging [64 px][SPX] + carry [2 halves][128 B] + scale|shift
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) v
     const float* xin = U8 ? nullptr : reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
     const uint8_t* xin8 = U8 ? reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3 : nullptr;
     char* const stgw = smem + 2 * FP_BYTES + ct * WAVE_LDS;
-    char* const carry = stgw + 4096;
+    char* const carry = stgw + 64 * SPX;
 
     bf16x8_t wf[7][2];
     {
@@ -545,13 +548,13 @@ __global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) v
                 for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)    // channels 8q + 4 lhi .. +4  -> bytes (8q + 4 lhi) * 2
-                        *reinterpret_cast<uint2*>(stgw + ((pr0 + pr) * 16 + (l31 >> 1)) * 64 + (8 * q + 4 * lhi) * 2) =
+                        *reinterpret_cast<uint2*>(stgw + ((pr0 + pr) * 16 + (l31 >> 1)) * SPX + (8 * q + 4 * lhi) * 2) =
                             make_uint2(pk2[pr][2 * q], pk2[pr][2 * q + 1]);
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {       // a pooled row: 16 pixels x 64 B = 64 lanes x 16 B
-                const uint4 o = *reinterpret_cast<const uint4*>(stgw + (pr0 + pr) * 1024 + lane * 16);
+                const uint4 o = *reinterpret_cast<const uint4*>(stgw + ((pr0 + pr) * 16 + (lane >> 2)) * SPX + (lane & 3) * 16);
                 const int py = (oy0 >> 1) + pr0 + pr, px = (ox0 >> 1) + (lane >> 2);
                 *reinterpret_cast<uint4*>(y + (((size_t)img * Hp + py) * Wp + px) * COUT + ct * 32 + (lane & 3) * 8) = o;
             }
@@ -733,7 +736,7 @@ static int launch_stem_pool_band(const void* x, FrameMean mean, int B, int N, in
 template <int COUT, bool U8>
 static int launch_stem_pool2(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                              const float* shift, uint16_t* y, hipStream_t s) {
-    constexpr int lds = 2 * fp_bytes<8>() + (COUT / 32) * (4096 + 256 + 256);
+    constexpr int lds = 2 * fp_bytes<8>() + (COUT / 32) * (64 * 80 + 256 + 256);
     dim3 grid((H / 2) / 8, N * B);
     hipLaunchKernelGGL((stem_pool2_kernel<COUT, U8>), grid, dim3(COUT * 2), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
     return w2c_launch_status();
