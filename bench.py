@@ -167,7 +167,7 @@ def main():
     flop_per_img = GFLOP_PER_AGENT_IMAGE_512 * (S / 512.0) ** 2
     roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
-                    traffic_note="PMC FETCH_SIZE/WRITE_SIZE per launch are in profiles/r01_h_pmc_hbm_traffic.txt "
+                    traffic_note="PMC FETCH_SIZE/WRITE_SIZE per launch are in profiles/r01_j_pmc_hbm_traffic.txt "
                                  "(needs rocprofv3, cannot be read from inside bench.py): 1.0-1.1x the algorithmic bytes",
                     launches_per_step=launches, kernel_ms_per_step=round(conv_ms, 4),
                     algorithmic_gflop_per_step=round(conv_fl / 1e9, 2),
