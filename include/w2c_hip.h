@@ -9,8 +9,8 @@
  * file:line each one stands in for is cited per function.  Plain pointers and
  * sizes only -- no torch types.  Every pointer is a DEVICE pointer on the
  * current HIP device unless stated; `stream` is a hipStream_t passed as void*.
- * All functions are re-entrant, keep no global mutable state, launch
- * asynchronously on `stream` and return 0 (W2C_OK) or a negative W2C_E_* code
+ * All functions are re-entrant, keep no global mutable state (scratch such as the split-K workspace is passed in
+ * by the caller, one per stream), launch asynchronously on `stream` and return 0 (W2C_OK) or a negative W2C_E_* code
  * (never abort).  w2c_status_string() maps a code to text.
  *
  * Data layout inside the path: activations are bf16 NHWC ("pixel-major":
@@ -86,7 +86,9 @@ int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y,
  * y        : bf16 (y_is_f32=0) or f32 (y_is_f32=1) NHWC, pixel stride
  *            y_cstride; group g writes channels [g*Cout, (g+1)*Cout)
  * zero_page: >= 256 bytes of zeros (source for padded taps)
- * Cin multiple of 64; Cout multiple of 32. */
+ * Cin multiple of 64; Cout multiple of 32.  x and w are addressed through 32-bit buffer descriptors: an x tensor of
+ * >= 2 GiB (M*H*W*x_cstride*2 bytes) or >= 2^29 output pixels returns W2C_E_ARG -- split M (results do not depend on
+ * M, see the _variant entry point). */
 int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
                         const uint16_t* w, int Cout, int ksize, int stride, int groups,
                         const float* scale, const float* shift,
@@ -95,7 +97,10 @@ int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_c
                         const void* zero_page, w2c_stream_t stream);
 
 /* Same contract, with the tile/pipeline variant forced (index into the table in csrc/conv_igemm.hip).
- * For tuning (tools/bench_conv.py) and tests; results are bit-identical across variants. */
+ * For tuning (tools/bench_conv.py) and tests.  Every variant walks K as (64-channel chunk, tap) and issues the same
+ * v_mfma_f32_32x32x16_bf16 sequence per output element, so results are bit-identical across variants -- and therefore
+ * independent of the image count M, which is what w2c_conv_igemm_bf16 keys its variant choice on
+ * (tests/test_kernels_gpu.py::test_conv_result_is_independent_of_tile_variant_and_image_count). */
 int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
                                 const uint16_t* w, int Cout, int ksize, int stride, int groups,
                                 const float* scale, const float* shift,
@@ -106,8 +111,8 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
 /* Split-K form of K2 for the tail layers (policy_net4 conv3..5 agent.py:128-132, simple_decoder's last conv
  * backbone.py:152): few output tiles under a long weight-streaming K loop.  `ksplit` workgroups share a tile, each
  * summing a contiguous range of K-steps into `workspace` (f32 partial tiles); a second launch adds them in split
- * order (deterministic) and runs the same epilogue.  ksplit = 0 picks the split (1 = falls through to
- * w2c_conv_igemm_bf16).  workspace: device memory, 16-B aligned, >= w2c_conv_splitk_workspace_bytes(...) bytes, contents
+ * order (deterministic) and runs the same epilogue.  ksplit = 0 picks the split from the LAYER geometry only (never
+ * from M: a shard of the images rounds exactly like the full batch; 1 = falls through to w2c_conv_igemm_bf16).  workspace: device memory, 16-B aligned, >= w2c_conv_splitk_workspace_bytes(...) bytes, contents
  * irrelevant; one workspace may serve consecutive launches on one stream, not concurrent ones. */
 int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
                                const uint16_t* w, int Cout, int ksize, int stride, int groups,

@@ -8,9 +8,10 @@
 // GEMM view:  D[pixel][cout] = sum_{tap,ci} X[pixel @ tap][ci] * Wt[cout][tap][ci]
 //   rows   = output pixels (M*Ho*Wo, NHWC order => a row IS the output pixel index)
 //   cols   = output channels of one group
-//   K      = ksize*ksize*Cin, walked as (tap, BK-channel chunk): NHWC makes every K-step of a
-//            row one contiguous run of BK*2 bytes, so the im2col gather is a per-lane ADDRESS
-//            (row base + a wave-uniform tap offset), never a materialised matrix.
+//   K      = ksize*ksize*Cin, walked as (64-channel chunk, tap) -- tap fastest, the SAME order in every
+//            kernel of this file, so results are bit-identical across tile variants: NHWC makes
+//            every K-step of a row one contiguous run of BK*2 bytes, so the im2col gather is a per-lane
+//            ADDRESS (row base + a wave-uniform tap offset), never a materialised matrix.
 // Per workgroup (64*WM*WN threads): a BM x BN tile.
 //   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 B per lane; the LDS image
 //     is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and again on
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int KSUB = BK / 16;                      // MFMA K-steps per stage
     constexpr int CLD = BN + 4;                        // f32 epilogue tile leading dim
-    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(BK == 64, "BK: one K-step = one 64-channel chunk of one tap (the K order every kernel shares)");
     static_assert(A_INSTR >= 1 && B_INSTR >= 1 && A_INSTR * RPI * NW == BM && B_INSTR * RPI * NW == BN, "DMA split");
     static_assert(STAGES >= 2 && (STAGES - 2) * LOADS < 64, "vmcnt range");
 
@@ -156,8 +157,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const int z = SPLITK ? (int)blockIdx.z : 0;
     const int t_begin = SPLITK ? (z * p.ktiles) / n_split : 0;
     const int t_end = SPLITK ? ((z + 1) * p.ktiles) / n_split : p.ktiles;
-    int st_kt = t_begin, st_ct = t_begin % p.cin_tiles;
-    int st_ky = (t_begin / p.cin_tiles) / p.ks, st_kx = (t_begin / p.cin_tiles) % p.ks;
+    // K order = (channel chunk, tap) with the TAP fastest -- the order the patch kernels need (one staged patch per
+    // chunk) -- so that every kernel of this file adds the same MFMA products in the same sequence and the results do
+    // not depend on which variant pick_variant() chose (i.e. on the image count: shard == unsharded batch, bit for bit)
+    const int ntap = p.ks * p.ks;
+    int st_ct = t_begin / ntap;
+    int st_ky = (t_begin - st_ct * ntap) / p.ks, st_kx = (t_begin - st_ct * ntap) % p.ks;
 
     auto stage = [&](int buf) {
         char* As = smem + buf * STAGE_BYTES;
@@ -174,11 +179,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(Bs + (wave + NW * j) * 1024), 16, b_off[j],
-                                                     st_kt * BK * 2, 0, 0);
-        ++st_kt;
-        if (++st_ct == p.cin_tiles) {
-            st_ct = 0;
-            if (++st_kx == p.ks) { st_kx = 0; ++st_ky; }
+                                                     ((st_ky * p.ks + st_kx) * p.Cin + st_ct * BK) * 2, 0, 0);
+        if (++st_kx == p.ks) {
+            st_kx = 0;
+            if (++st_ky == p.ks) { st_ky = 0; ++st_ct; }
         }
     };
 
@@ -982,285 +986,6 @@ int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
 }
 
 
-// Layer2 sibling of the kernel above: 3x3 stride-1, Cin = Cout = 128 per group.  K = 1152, so ONE 32-channel tile's
-// weights fill the 288 registers: wave w of the workgroup owns channel tile w, and the four waves share the pixels.
-//   * workgroup tile = 4 x 16 pixels x 128 channels; the 6 x 18 x 128-channel patch (27 KB) is double-buffered in
-//     LDS and filled by all four waves' LDS-DMA pieces (7 each) -> one workgroup barrier per tile, at its top: it
-//     publishes patch(t) and retires the buffer patch(t+1) is about to overwrite;
-//   * everything else is private to the wave: its residual slice (64 pixels x 64 B), its f32 staging (both pixel
-//     tiles at once, no reuse hazard), its stores;  144 MFMAs per tile and wave, 1 B-fragment read per MFMA.
-// LDS patch row = 256 B per pixel; 16-B chunk C of the pixel in patch column c sits at slot C ^ (c & 15).
-template <bool HAS_RES>
-__global__ __launch_bounds__(256) void conv3x3_c128_regw_kernel(ConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int PW = 18;
-    constexpr int PATCH_BYTES = 28 * 1024;         // 28 DMA instructions x 4 pixels x 256 B (108 pixels used)
-    constexpr int RES_WAVE = 4 * 1024;             // 64 pixels x 64 B (this wave's 32 channels)
-    constexpr int SP = 144;                        // staging row pitch: 32 f32 + 16 B
-    constexpr int STAGE_WAVE = 2 * 32 * SP;
-    constexpr int OFF_RES = 2 * PATCH_BYTES, OFF_STAGE = OFF_RES + 4 * RES_WAVE, OFF_SS = OFF_STAGE + 4 * STAGE_WAVE;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int g = blockIdx.y;
-    char* const resw = smem + OFF_RES + wave * RES_WAVE;
-    char* const stagew = smem + OFF_STAGE + wave * STAGE_WAVE;
-    const unsigned long long wall0 = p.dbg ? wall_clock64() : 0;
-
-    // ---- this wave's 32 x 1152 weights -> registers (A operand); K-chunks 0-3 of every tap pinned to AGPRs, 4-7 to VGPRs ----
-    u32x4_t wa[9][4], wv[9][4];
-    {
-        const uint16_t* wrow = p.w + ((size_t)g * 128 + wave * 32 + l31) * 1152 + lhi * 8;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                wa[tap][kc] = *reinterpret_cast<const u32x4_t*>(wrow + tap * 128 + kc * 16);
-                wv[tap][kc] = *reinterpret_cast<const u32x4_t*>(wrow + tap * 128 + 64 + kc * 16);
-            }
-        if (tid < 128) {
-            reinterpret_cast<float*>(smem + OFF_SS)[tid] = p.scale[g * 128 + tid];
-            reinterpret_cast<float*>(smem + OFF_SS)[128 + tid] = p.shift[g * 128 + tid];
-        }
-    }
-
-    // ---- workgroup tiles: a contiguous run, XCD-contiguous across the grid ----
-    const int ntx = p.W >> 4, nty = p.H >> 2, tpi = ntx * nty;
-    const int T = p.M * tpi;
-    const int nwg = gridDim.x;
-    const int b = blockIdx.x;
-    const int logical = (nwg % 8 == 0) ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
-    const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long)logical * T) / nwg));
-    const int t_end = __builtin_amdgcn_readfirstlane((int)(((long)(logical + 1) * T) / nwg));
-    if (t_begin >= t_end) return;                  // whole workgroup: no barrier is skipped by a part of it
-
-    const size_t x_bytes = (size_t)p.M * p.H * p.W * p.xcs * 2;
-    const size_t y_bytes = (size_t)p.M * p.H * p.W * p.ycs * (p.y_f32 ? 4 : 2);
-    const size_t r_bytes = (size_t)p.M * p.H * p.W * p.ycs * 2;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(p.x + (size_t)g * 128), 0, (int)(x_bytes - (size_t)g * 256), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>((HAS_RES ? p.res : p.x) + (size_t)g * 128), 0, (int)((HAS_RES ? r_bytes : x_bytes) - (size_t)g * 256),
-        0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)y_bytes, 0x00020000);
-    // patch piece k of this wave = DMA instruction j = wave + 4k: pixels q = 4j + lane/16, LDS slot lane%16
-    int off_rel[7];
-    unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_inval = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int q = 4 * (wave + 4 * k) + (lane >> 4);
-        const int dy = (q * 3641) >> 16, dx = q - dy * PW;
-        const int chunk = (lane & 15) ^ (dx & 15);                  // keyed on the patch column (conflict-free two-row reads)
-        off_rel[k] = ((dy * p.W + dx) * p.xcs + chunk * 8) * 2;
-        m_top |= (dy == 0 ? 1u : 0u) << k;
-        m_bot |= (dy == 5 ? 1u : 0u) << k;
-        m_left |= (dx == 0 ? 1u : 0u) << k;
-        m_right |= (dx == 17 ? 1u : 0u) << k;
-        m_inval |= (q >= 6 * PW ? 1u : 0u) << k;
-    }
-    const unsigned r_lane = (unsigned)(((lane >> 2) * p.ycs + wave * 32 + (lane & 3) * 8) * 2);   // residual: pixel lane/4, chunk lane%4
-    const int cg = lane & 3;                                                                     // read-out: 8-channel group
-    const unsigned y_lane = (unsigned)(((lane >> 2) * p.ycs + g * 128 + wave * 32 + cg * 8) * (p.y_f32 ? 4 : 2));
-    const char* const ssb = smem + OFF_SS + (wave * 32 + cg * 8) * 4;
-
-    int pbase = 0;
-    unsigned pbad = 0;
-    auto patch_piece = [&](int k, char* dst) {
-        const unsigned vo = ((pbad >> k) & 1u) ? 0x80000000u : (unsigned)(pbase + off_rel[k]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(dst + (wave + 4 * k) * 1024), 16, vo, 0, 0, 0);
-    };
-    int rbase = 0;
-    auto residual_piece = [&](int r) {             // tile row r: 16 pixels x 64 B of this wave's channels
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, W2C_LPTR(resw + r * 1024), 16, r_lane, rbase + r * p.W * p.ycs * 2, 0, 0);
-    };
-    auto halo_mask = [&](int yy, int xx) {
-        return m_inval | (yy == 0 ? m_top : 0u) | (yy + 4 == p.H ? m_bot : 0u) | (xx == 0 ? m_left : 0u) |
-               (xx + 16 == p.W ? m_right : 0u);
-    };
-
-    int qb[2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) qb[pt] = (pt * 2 + (l31 >> 4)) * PW + (l31 & 15);
-
-    int img = t_begin / tpi, y0, x0;
-    {
-        const int r = t_begin - img * tpi;
-        const int tx = r / nty;                    // column-major: a wave's consecutive tiles are vertically adjacent, so
-        x0 = tx * 16;                              // 2 of the 6 patch rows of the next tile were just read by this wave
-        y0 = (r - tx * nty) * 4;                   // (measured: layer1 L2-miss read traffic 1.47x -> see profiles/)
-    }
-    int cur = 0;
-    pbase = (((img * p.H + y0 - 1) * p.W) + x0 - 1) * p.xcs * 2;
-    pbad = halo_mask(y0, x0);
-#pragma unroll
-    for (int k = 0; k < 7; ++k) patch_piece(k, smem);
-    unsigned long long ph[4] = {0, 0, 0, 0};       // debug (p.dbg): cycles at tile top (barrier) | MFMA loop | vmcnt wait | epilogue
-    unsigned long long wall2 = 0;
-    const unsigned long long wall1 = p.dbg ? wall_clock64() : 0;
-    long long tp = p.dbg ? clock64() : 0;
-    auto stamp = [&](int i) {
-        if (p.dbg) { const long long n = clock64(); ph[i] += (unsigned long long)(n - tp); tp = n; }
-    };
-    for (int t = t_begin; t < t_end; ++t) {
-        char* const pc = smem + cur * PATCH_BYTES;
-        char* const pn = smem + (cur ^ 1) * PATCH_BYTES;
-        if (t != t_begin) {
-            y0 += 4;
-            if (y0 == p.H) { y0 = 0; x0 += 16; if (x0 == p.W) { x0 = 0; ++img; } }
-        }
-        rbase = ((img * p.H + y0) * p.W + x0) * p.ycs * 2;
-        {
-            int xn = x0, yn = y0 + 4, in = img;
-            if (yn == p.H) { yn = 0; xn += 16; if (xn == p.W) { xn = 0; ++in; } }
-            pbase = (((in * p.H + yn - 1) * p.W) + xn - 1) * p.xcs * 2;
-            pbad = (t + 1 < t_end) ? halo_mask(yn, xn) : 0xFFFFFFFFu;       // last tile: every lane off
-        }
-        if (t == t_begin) wait_vmcnt<0>();         // my pieces of patch(t) (later tiles: waited for before epilogue(t-1))
-        if (p.dbg && t == t_begin) wall2 = wall_clock64();
-        pipeline_barrier();                        // patch(t) complete; every wave is done with the other buffer (tile t-1)
-        stamp(0);
-
-        f32x16_t acc[2];
-        int qv0 = qb[0], qv1 = qb[1];
-        asm volatile("" : "+v"(qv0), "+v"(qv1));   // keep the 144 fragment addresses out of registers (see the layer1 kernel)
-        int fb[2], fx[2];
-        auto tap_setup = [&](int tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int q0 = qv0 + ky * PW + kx, q1 = qv1 + ky * PW + kx;
-            const int cs = ((((l31 & 15) + kx) ^ lhi) & 15) << 4;
-            fb[0] = q0 * 256; fx[0] = cs;
-            fb[1] = q1 * 256; fx[1] = cs;
-        };
-        auto frag = [&](int kc, int pt) { return *reinterpret_cast<const u32x4_t*>(pc + fb[pt] + ((kc << 5) ^ fx[pt])); };
-        u32x4_t bx[2][2];
-        tap_setup(0);
-        bx[0][0] = frag(0, 0);
-        bx[0][1] = frag(0, 1);
-#pragma unroll
-        for (int step = 0; step < 72; ++step) {
-            const int tap = step >> 3, kc = step & 7, cb = step & 1;
-            if (step + 1 < 72) {
-                if (((step + 1) & 7) == 0) tap_setup((step + 1) >> 3);
-                bx[cb ^ 1][0] = frag((step + 1) & 7, 0);
-                bx[cb ^ 1][1] = frag((step + 1) & 7, 1);
-            }
-            if (HAS_RES && step >= 2 && step <= 8 && (step & 1) == 0) residual_piece((step - 2) >> 1);
-            if (step >= 12 && step <= 36 && (step & 3) == 0) patch_piece((step - 12) >> 2, pn);
-            if (kc < 4) {
-                if (step == 0) {
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[0]) : "a"(wa[tap][kc]), "v"(bx[cb][0]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[1]) : "a"(wa[tap][kc]), "v"(bx[cb][1]));
-                } else {
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0]) : "a"(wa[tap][kc]), "v"(bx[cb][0]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[1]) : "a"(wa[tap][kc]), "v"(bx[cb][1]));
-                }
-            } else {
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(wv[tap][kc - 4]), "v"(bx[cb][0]));
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[1]) : "v"(wv[tap][kc - 4]), "v"(bx[cb][1]));
-            }
-        }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // XDL-write -> VALU/DS-read wait states (opaque to the compiler)
-        stamp(1);
-
-        // ---- epilogue: both pixel tiles staged at once (wave-private), then 4 read-out items of 8 channels per lane ----
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int eg = 0; eg < 4; ++eg)
-                *reinterpret_cast<f32x4_t*>(stagew + (pt * 32 + l31) * SP + (eg * 8 + lhi * 4) * 4) =
-                    f32x4_t{acc[pt][eg * 4], acc[pt][eg * 4 + 1], acc[pt][eg * 4 + 2], acc[pt][eg * 4 + 3]};
-        asm volatile("" ::: "memory");
-        wait_vmcnt<0>();       // residual(t), my pieces of patch(t+1) (issued >= 35 K-steps ago), and the stores of tile t-1
-        asm volatile("" ::: "memory");
-        stamp(2);
-        const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssb), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssb + 16);
-        const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(ssb + 512), e_sh1 = *reinterpret_cast<const f32x4_t*>(ssb + 528);
-        const int tile_pix = (img * p.H + y0) * p.W + x0;
-        f32x4_t v0[4], v1[4];
-        uint4 rr[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {           // item it: tile row `it` (= pixel tile it/2, half it&1), pixel lane/4, channels cg*8..+8
-            const char* sp = stagew + ((it >> 1) * 32 + (it & 1) * 16 + (lane >> 2)) * SP + cg * 32;
-            v0[it] = *reinterpret_cast<const f32x4_t*>(sp);
-            v1[it] = *reinterpret_cast<const f32x4_t*>(sp + 16);
-            if constexpr (HAS_RES) rr[it] = *reinterpret_cast<const uint4*>(resw + (it * 16 + (lane >> 2)) * 64 + cg * 16);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            f32x4_t a0 = v0[it] * e_sc0 + e_sh0;
-            f32x4_t a1 = v1[it] * e_sc1 + e_sh1;
-            if constexpr (HAS_RES) {
-                const uint32_t rw[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
-                a0 += f32x4_t{__uint_as_float(rw[0] << 16), __uint_as_float(rw[0] & 0xFFFF0000u),
-                              __uint_as_float(rw[1] << 16), __uint_as_float(rw[1] & 0xFFFF0000u)};
-                a1 += f32x4_t{__uint_as_float(rw[2] << 16), __uint_as_float(rw[2] & 0xFFFF0000u),
-                              __uint_as_float(rw[3] << 16), __uint_as_float(rw[3] & 0xFFFF0000u)};
-            }
-            const int pix = tile_pix + it * p.W;
-            if (p.y_f32) {
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { a0[e] = fmaxf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f); }
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a0), rs_y, y_lane, pix * p.ycs * 4, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a1), rs_y, y_lane + 16, pix * p.ycs * 4, 0);
-            } else {
-                uint32_t ow[4] = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]),
-                                  pack_bf16x2(a1[2], a1[3])};
-                if (p.relu) {                      // ReLU on the rounded pairs (see the layer1 kernel)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const s16x2_t h = __builtin_bit_cast(s16x2_t, ow[e]);
-                        ow[e] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(h, s16x2_t{0, 0}));
-                    }
-                }
-                const u32x4_t o = {ow[0], ow[1], ow[2], ow[3]};
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, y_lane, pix * p.ycs * 2, 0);
-            }
-        }
-        asm volatile("" ::: "memory");
-        stamp(3);
-        cur ^= 1;
-    }
-    if (p.dbg && lane == 0 && wave == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-        for (int i = 0; i < 4; ++i) d[i] = ph[i];
-        d[4] = wall0; d[5] = wall1; d[6] = wall_clock64(); d[7] = 1;
-        d[3] = wall2 - wall1;                      // (debug) ticks from "setup done" to "weights + first patch landed"
-    }
-#endif
-}
-
-template <bool HAS_RES>
-int launch_regw128(ConvArgs& a, int groups, hipStream_t s) {
-    constexpr int lds = 2 * 28 * 1024 + 4 * 4096 + 4 * (2 * 32 * 144) + 1024;      // 111616
-    static unsigned long long attr_mask = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static int n_cu[64] = {0};
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c128_regw_kernel<HAS_RES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipDeviceProp_t prop;
-        n_cu[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                             ? prop.multiProcessorCount : 256;
-        attr_mask |= 1ull << (dev & 63);
-    }
-    const long tiles = (long)a.M * (a.H / 4) * (a.W / 16);
-    int wgs = (n_cu[dev & 63] + groups - 1) / groups;
-    wgs = (wgs + 7) / 8 * 8;
-    if (wgs > tiles) wgs = (int)tiles;
-    hipLaunchKernelGGL((conv3x3_c128_regw_kernel<HAS_RES>), dim3(wgs, groups), dim3(256), lds, s, a);
-    return w2c_launch_status();
-}
-
-int launch_regw128_any(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.ks != 3 || a.stride != 1 || a.Cin != 128 || a.Cout != 128 || a.H % 4 != 0 || a.W % 16 != 0) return W2C_E_ARG;
-    if ((size_t)a.M * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.M * a.H * a.W * a.ycs * 4 >= (1ull << 31)) return W2C_E_ARG;
-    return a.res ? launch_regw128<true>(a, groups, s) : launch_regw128<false>(a, groups, s);
-}
-
 template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
@@ -1365,7 +1090,11 @@ int launch_conv_splitk(ConvArgs& a, int groups, int ksplit, hipStream_t s) {
     return w2c_launch_status();
 }
 
-// tile shape + split count for a split-K launch; ksplit == 1 means "not worth splitting"
+// tile shape + split count for a split-K launch; ksplit == 1 means "not worth splitting".
+// The split count is a function of the LAYER (channels, taps, output map size) only, never of the image count M: the
+// partial sums of a split are added in split order, so a split that moved with M would make a shard of the agents
+// round differently from the unsharded batch.  It is sized for a nominal 16-image batch (~2 workgroups per CU, >= 3
+// K-steps per split); other batch sizes get the same arithmetic with more or fewer workgroups.
 struct SplitPlan { int bm, bn, tiles, ksplit; };
 SplitPlan plan_splitk(const ConvArgs& a, int groups, int want) {
     SplitPlan sp;
@@ -1374,10 +1103,12 @@ SplitPlan plan_splitk(const ConvArgs& a, int groups, int want) {
     sp.tiles = (int)(((long)a.rows + sp.bm - 1) / sp.bm) * (a.Cout / sp.bn) * groups;
     const int kt = a.ks * a.ks * (a.Cin / 64);
     int ks = want;
-    if (ks <= 0) {                                         // auto: ~2 workgroups per CU, >= 3 K-steps each
-        ks = (512 + sp.tiles - 1) / sp.tiles;
+    if (ks <= 0) {
+        const long rows16 = 16L * a.Ho * a.Wo;
+        const long tiles16 = ((rows16 + sp.bm - 1) / sp.bm) * (a.Cout / sp.bn) * groups;
+        ks = (int)((512 + tiles16 - 1) / tiles16);
         if (ks > kt / 3) ks = kt / 3;
-        if (sp.tiles >= 256) ks = 1;
+        if (tiles16 >= 256) ks = 1;
     }
     if (ks < 1) ks = 1;
     if (ks > kt) ks = kt;
@@ -1408,51 +1139,25 @@ int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
     return w2c_launch_status();
 }
 
-// Variant table (index = `variant` of w2c_conv_igemm_bf16_variant; tools/bench_conv.py sweeps it).
+// Variant table (index = `variant` of w2c_conv_igemm_bf16_variant; tools/bench_conv.py sweeps it).  Only the variants
+// pick_variant() dispatches are built; the ~30 other tile / ring shapes measured in round 1
+// (profiles/r01_b_conv_variant_sweep.txt: BK=32 rings, 8-wave 256-row tiles, 8x32 / 16x16 / 4x32 patches, deeper rings,
+// the layer2 register-resident sibling) lost everywhere and were removed.
 int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
     switch (variant) {
-        case 0: return launch_conv<128, 128, 2, 2, 64, 2>(a, groups, s);   // r01 baseline structure
-        case 1: return launch_conv<128, 128, 2, 2, 32, 4>(a, groups, s);
-        case 2: return launch_conv<128, 128, 2, 2, 64, 3>(a, groups, s);
+        // generic implicit GEMM (stride 2, 1x1, narrow maps): BM x BN, 4 waves, 2-deep ring
+        case 0: return launch_conv<128, 128, 2, 2, 64, 2>(a, groups, s);
         case 3: return launch_conv<128, 64, 2, 2, 64, 2>(a, groups, s);
-        case 4: return launch_conv<128, 64, 2, 2, 64, 3>(a, groups, s);
-        case 5: return launch_conv<128, 64, 2, 2, 32, 4>(a, groups, s);
         case 6: return launch_conv<64, 64, 2, 2, 64, 2>(a, groups, s);
-        case 7: return launch_conv<64, 64, 2, 2, 64, 4>(a, groups, s);
         case 8: return launch_conv<128, 32, 4, 1, 64, 2>(a, groups, s);
-        case 9: return launch_conv<128, 32, 4, 1, 64, 4>(a, groups, s);
-        case 10: return launch_conv<256, 128, 4, 2, 64, 3>(a, groups, s);  // 8 waves
-        case 11: return launch_conv<256, 128, 4, 2, 32, 4>(a, groups, s);  // 8 waves
-        case 12: return launch_conv<128, 128, 2, 2, 32, 3>(a, groups, s);
-        case 13: return launch_conv<64, 64, 2, 2, 64, 3>(a, groups, s);
-        case 14: return launch_conv<128, 64, 2, 2, 64, 4>(a, groups, s);
-        case 15: return launch_conv<256, 64, 4, 1, 64, 3>(a, groups, s);   // 4 waves, 64x64 wave tile
-        // patch-staged 3x3 stride-1 kernels (TH x TW pixel tile, BN, weight-ring stages)
-        case 20: return launch_patch<8, 32, 128, 4, 2, 3>(a, groups, s);
-        case 21: return launch_patch<8, 32, 128, 4, 2, 2>(a, groups, s);
-        case 22: return launch_patch<8, 32, 64, 4, 2, 3>(a, groups, s);
-        case 23: return launch_patch<16, 16, 128, 4, 2, 3>(a, groups, s);
-        case 24: return launch_patch<16, 16, 64, 4, 2, 3>(a, groups, s);
-        case 25: return launch_patch<8, 32, 64, 4, 2, 4>(a, groups, s);
-        case 26: return launch_patch<16, 16, 128, 4, 2, 2>(a, groups, s);
-        // 4-wave, 128-pixel tiles: <= 80 KB of LDS so TWO workgroups share a CU (one's prologue /
-        // epilogue under the other's MFMAs)
-        case 30: return launch_patch<8, 16, 128, 2, 2, 2>(a, groups, s);
-        case 31: return launch_patch<8, 16, 64, 2, 2, 3>(a, groups, s);
-        case 32: return launch_patch<4, 32, 128, 2, 2, 2>(a, groups, s);
-        case 33: return launch_patch<4, 32, 64, 2, 2, 3>(a, groups, s);
-        case 34: return launch_patch<8, 16, 64, 2, 2, 2>(a, groups, s);
-        // same 128-pixel / 2-WG-per-CU tiles with 8 waves (wave tile 32 x BN/2): half the DMA instructions per wave
-        case 35: return launch_patch<8, 16, 128, 4, 2, 2>(a, groups, s);
-        case 36: return launch_patch<8, 16, 64, 4, 2, 3>(a, groups, s);
-        case 37: return launch_patch<8, 16, 128, 2, 4, 2>(a, groups, s);
+        // patch-staged 3x3 stride-1 kernels: 8 x 16-pixel tiles, <= 80 KB of LDS so TWO workgroups share a CU (one's
+        // prologue / epilogue under the other's MFMAs)
+        case 30: return launch_patch<8, 16, 128, 2, 2, 2>(a, groups, s);     // 4 waves, 128 output channels per tile
+        case 36: return launch_patch<8, 16, 64, 4, 2, 3>(a, groups, s);      // 8 waves, 64 channels, 3-deep weight ring
         // Cin == 64 (one channel chunk): a single patch buffer -> ~39 KB of LDS -> four workgroups per CU
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
-        case 39: return launch_patch<8, 16, 64, 4, 2, 2, 1>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
-        // layer2 (Cin = Cout = 128): one 32-channel tile's weights per wave, shared pixel patch, one barrier per tile
-        case 51: return launch_regw128_any(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -1503,6 +1208,12 @@ int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int 
     a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
     a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
     a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;
+    // the kernels address x and w through buffer descriptors with 32-bit byte offsets (extent < 2 GiB; an offset of
+    // 0x80000000 is the "padding -> zeros" marker) and count output rows in an int: refuse what would overflow
+    // instead of silently reading zeros.  Callers chunk M (ops.conv_igemm does).
+    if ((size_t)M * H * W * x_cstride * 2 >= (1ull << 31) || (size_t)Cout * ksize * ksize * Cin * 2 >= (1ull << 31) ||
+        (size_t)M * a.Ho * a.Wo >= (1ull << 29))
+        return W2C_E_ARG;
     a.rows = M * a.Ho * a.Wo;
     a.dbg = nullptr;
     a.ws = nullptr;
@@ -1534,7 +1245,9 @@ extern "C" long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Ci
     ConvArgs a;
     a.ks = ksize; a.Cin = Cin; a.Cout = Cout;
     const int pad = ksize == 3 ? 1 : 0;
-    a.rows = M * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+    a.Ho = (H + 2 * pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * pad - ksize) / stride + 1;
+    a.rows = M * a.Ho * a.Wo;
     const SplitPlan sp = plan_splitk(a, groups, ksplit);
     if (sp.ksplit <= 1) return 0;
     return (long long)sp.tiles * sp.ksplit * sp.bm * sp.bn * 4;

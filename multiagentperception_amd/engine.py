@@ -151,6 +151,10 @@ class HeadPlan:
             fc = head.fc
             w0 = fc[0].weight.detach().float()
             n_feat = w0.shape[1]
+            if hw <= 0 or n_feat % hw != 0:
+                raise ops.W2CError("head: fc.0 expects %d features, the policy map has %d pixels (input resolution does not "
+                                   "match the model's image_size; the reference fails in view(-1, n_feat), agent.py:157)"
+                                   % (n_feat, hw))
             c = n_feat // hw
             w0s.append(w0.reshape(w0.shape[0], c, hw).permute(0, 2, 1).reshape(w0.shape[0], n_feat))
             b0s.append(fc[0].bias.detach().float())
@@ -168,6 +172,9 @@ class HeadPlan:
 
     def run(self, qk_map):
         M = qk_map.shape[0]
+        if qk_map.shape[1] * qk_map.shape[2] * qk_map.shape[3] != self.n_feat:
+            raise ops.W2CError("head: policy map %s does not flatten to fc.0's %d input features (input resolution differs "
+                               "from the model's image_size)" % (tuple(qk_map.shape), self.n_feat))
         h0 = ops.linear(qk_map, self.w0, self.b0, relu=True, x_stride=self.n_feat, rows=M)     # [M, 256*nheads]
         if len(self.tails) == 2 and self.tails[0][0] == self.tails[1][0]:      # key + query heads: one launch
             (k1, wa1, ba1, wa2, ba2), (_, wb1, bb1, wb2, bb2) = self.tails
@@ -207,13 +214,27 @@ class CommEngine:
         pn = model.query_key_net
         self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
                        for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
-        self.heads = None           # built lazily: fc.0's column permutation needs the map's h*w
+        self._heads = {}            # built lazily per policy-map size: fc.0's column permutation needs the map's h*w
         self._model_heads = (model.key_net, model.query_net if self.has_query else None)
         self.wq = model.attention_net.linear.weight.detach().float().contiguous()
         self.bq = model.attention_net.linear.bias.detach().float().contiguous()
         self.decoder = DecoderPlan(model.decoder, self.n_classes)
         self.feat = 512
         self._graphs = {}
+
+    def _head_plan(self, y):
+        """HeadPlan for policy map y [M,h,w,256]; raises (like the reference's view(-1, n_feat)) when h*w*256 is not
+        what fc.0 was built for."""
+        hw = y.shape[1] * y.shape[2]
+        plan = self._heads.get(hw)
+        if plan is None:
+            n_feat = self._model_heads[0].fc[0].in_features
+            if hw * y.shape[3] != n_feat:
+                raise ops.W2CError("policy map %s has %d features, the key/query heads expect %d: input resolution does not "
+                                   "match the model's image_size" % (tuple(y.shape), hw * y.shape[3], n_feat))
+            plan = HeadPlan([h for h in self._model_heads if h is not None], hw, key_projection=(self.wq, self.bq))
+            self._heads[hw] = plan
+        return plan
 
     def policy_tail(self, sq):
         """policy_net4 conv1..5 + key/query heads on the policy-encoder half of `sq` (agent.py:137-141,
@@ -222,10 +243,7 @@ class CommEngine:
         y = self.policy[0].run(sq, x_ch_off=self.feat)
         for c in self.policy[1:]:
             y = c.run(y)
-        hw = y.shape[1] * y.shape[2]
-        if self.heads is None:
-            self.heads = HeadPlan([h for h in self._model_heads if h is not None], hw, key_projection=(self.wq, self.bq))
-        outs = self.heads.run(y)
+        outs = self._head_plan(y).run(y)
         return outs[0], (outs[1] if len(outs) > 1 else None)
 
     def encode(self, x, n_agents):
@@ -314,6 +332,7 @@ class SRMSEngine:
     (agent 0's normal-encoder map is unused) and degarded_encoder runs alone on the requester's frames."""
 
     N = 5
+    _head_plan = CommEngine._head_plan
 
     def __init__(self, model):
         self.who = bool(model._who)
@@ -333,7 +352,7 @@ class SRMSEngine:
                                "reference config selects it" % (enc,))
         self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
                        for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
-        self.heads = None
+        self._heads = {}
         self._model_heads = (model.key_net, model.query_net if self.has_query else None)
         self.wq = model.attention_net.linear.weight.detach().float().contiguous()
         self.bq = model.attention_net.linear.bias.detach().float().contiguous()
@@ -354,10 +373,7 @@ class SRMSEngine:
         y = self.policy[0].run(sq, x_ch_off=self.feat)
         for c in self.policy[1:]:
             y = c.run(y)
-        if self.heads is None:
-            self.heads = HeadPlan([h for h in self._model_heads if h is not None], y.shape[1] * y.shape[2],
-                                  key_projection=(self.wq, self.bq))
-        outs = self.heads.run(y)
+        outs = self._head_plan(y).run(y)
         tproj = outs[0]                                                 # [5B, Dq+1] projected keys, agent-major
         query = outs[1][:B].contiguous() if self.has_query else None    # the requester's queries (agent 0)
         if self.who:

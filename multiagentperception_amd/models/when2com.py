@@ -31,7 +31,10 @@ class _EngineCacheMixin:
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._engines.clear())
 
     def train(self, mode=True):
-        self._engines.clear()
+        # parameters can only change under train(): eval() -> eval() (e.g. the evaluator's model.eval() at the top of
+        # every validation pass) keeps the packed weights and the captured HIP graphs
+        if mode:
+            self._engines.clear()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
@@ -42,7 +45,9 @@ class _EngineCacheMixin:
         if not x.is_cuda:
             raise W2CError("%s.forward (eval) runs only on an MI355X device tensor; got input on %s. "
                            "There is no CPU fallback for the When2com forward path." % (type(self).__name__, x.device))
-        p = next(self.parameters())
+        # NOT next(self.parameters()): nn.DataParallel replicas (train.py:177) have empty _parameters -- their weights are
+        # plain tensor attributes (torch/nn/parallel/replicate.py) -- so ask a weight every model of this file owns
+        p = self.decoder.output_decoder.pred[0].weight
         if p.device != x.device:
             raise W2CError("input on %s but parameters on %s" % (x.device, p.device))
         key = (x.device.index if x.device.index is not None else torch.cuda.current_device())

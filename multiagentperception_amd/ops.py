@@ -5,6 +5,8 @@ hands raw device pointers + sizes to libw2c_hip.so on torch's CURRENT stream of
 the tensor's device (so the path is re-entrant under DataParallel replicas and
 capturable in a graph).  There is no fallback: CPU tensors raise.
 """
+import threading
+
 import torch
 
 from . import _native
@@ -59,12 +61,11 @@ class KernelTimer:
         return total_ms, total_fl, len(self.records), per
 
 
-_conv_timer = None
+_tls = threading.local()          # per-thread (DataParallel runs one thread per replica): the opt-in conv timer
 
 
 def set_conv_timer(timer):
-    global _conv_timer
-    _conv_timer = timer
+    _tls.conv_timer = timer
 
 
 _zero_pages = {}
@@ -144,21 +145,27 @@ _splitk_ws = {}
 
 
 def splitk_workspace(dev, nbytes):
-    """Per-device split-K scratch (zeroed once; the kernel restores its counters to zero).  Launches that share it
-    are ordered by the stream they run on."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    """Split-K scratch, one per (device, stream): launches that share a workspace are ordered by the stream they run on,
+    so concurrent streams / DataParallel replica threads / a graph under capture never share one.  Contents are
+    irrelevant to the kernel (every partial tile is written before it is read)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(int(nbytes), 16 << 20), dtype=torch.uint8, device=dev)
+        ws = torch.empty(max(int(nbytes), 16 << 20), dtype=torch.uint8, device=dev)
         _splitk_ws[key] = ws
     return ws
+
+
+_MAX_X_BYTES = (1 << 31) - 1       # the conv kernels address x through a 32-bit buffer descriptor (include/w2c_hip.h)
 
 
 def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
                out=None, out_f32=False, out_cstride=None, variant=None, ksplit=None):
     """x: bf16 NHWC [M,H,W,xcs]; the conv reads channels [x_ch_off + g*cin, ...).  Returns/accepts
     out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32).  ksplit: None = one workgroup per tile;
-    0 = split-K chosen by the library for tail layers; n = forced n-way split."""
+    0 = split-K chosen by the library for tail layers; n = forced n-way split.
+    Batches whose activation tensor reaches 2 GiB are run as several launches over slices of M (results are
+    independent of the image count, so the slicing is invisible)."""
     dev = _need_gpu(x, w_packed, scale, shift, residual, out)
     M, H, W, xcs = x.shape
     pad = 1 if ksize == 3 else 0
@@ -166,14 +173,25 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     Wo = (W + 2 * pad - ksize) // stride + 1
     if out_cstride is None:
         out_cstride = groups * cout
+    if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
+        raise W2CError("conv: channels [%d, %d) outside the tensor's %d channels" % (x_ch_off, x_ch_off + groups * cin, xcs))
     if out is None:
         out = torch.empty((M, Ho, Wo, out_cstride), dtype=torch.float32 if out_f32 else BF16, device=dev)
     if tuple(out.shape) != (M, Ho, Wo, out_cstride):
         raise W2CError("conv: bad out shape %s, want %s" % (tuple(out.shape), (M, Ho, Wo, out_cstride)))
     if residual is not None and tuple(residual.shape) != tuple(out.shape):
         raise W2CError("conv: residual geometry must equal the output geometry")
+    per_img = max(H * W * xcs * 2, Ho * Wo * out_cstride * 2)
+    if M * per_img > _MAX_X_BYTES:
+        step = max(1, _MAX_X_BYTES // per_img)
+        for lo in range(0, M, step):
+            hi = min(M, lo + step)
+            conv_igemm(x[lo:hi], x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift,
+                       residual=None if residual is None else residual[lo:hi], relu=relu, out=out[lo:hi],
+                       out_f32=out_f32, out_cstride=out_cstride, variant=variant, ksplit=ksplit)
+        return out
     xptr = x.data_ptr() + 2 * x_ch_off
-    timer = _conv_timer
+    timer = getattr(_tls, "conv_timer", None)
     if timer is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
@@ -217,6 +235,8 @@ def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
         rows = x.shape[0]
     if x_stride is None:
         x_stride = K
+    if rows < 1 or x_stride < K or x.numel() < (rows - 1) * x_stride + K:
+        raise W2CError("linear: %d rows of stride %d (K=%d) do not fit the %d-element input" % (rows, x_stride, K, x.numel()))
     y = torch.empty((rows, O), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_linear_f32(_p(x), 1 if x.dtype == BF16 else 0, x_stride, rows, K, _p(w), _p(b), O,
@@ -230,6 +250,9 @@ def head_tail(h0, col_off, k1, w1t, b1, w2t, b2):
     M, stride = h0.shape
     H1 = w1t.shape[1]
     O = w2t.shape[1]
+    if col_off < 0 or col_off + k1 > stride or w1t.shape[0] != k1 or w2t.shape[0] != H1:
+        raise W2CError("head_tail: columns [%d, %d) / weights %s, %s do not fit h0 %s" %
+                       (col_off, col_off + k1, tuple(w1t.shape), tuple(w2t.shape), tuple(h0.shape)))
     out = torch.empty((M, O), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_head_tail_f32(h0.data_ptr() + 4 * col_off, stride, M, k1, _p(w1t), _p(b1), H1, _p(w2t),
@@ -246,6 +269,8 @@ def head_tail2(h0, k1, tail_a, tail_b):
     H1 = w1a.shape[1]
     if w1b.shape[1] != H1:
         raise W2CError("head_tail2: both heads must share the hidden width")
+    if min(ca, cb) < 0 or max(ca, cb) + k1 > stride or w1a.shape[0] != k1 or w1b.shape[0] != k1:
+        raise W2CError("head_tail2: column ranges / weights do not fit h0 %s" % (tuple(h0.shape),))
     out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
     out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

@@ -116,15 +116,13 @@ class AgentParallelForward:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.q_lo, self.n_loc = shard_agents(model.agent_num, self.world, self.rank)
         self._engine_cls = _engine.CommEngine
-        self.eng = None
 
     def __call__(self, inputs_local, inference="softmax"):
         model = self.model
         if model.training:
             raise RuntimeError("agent-parallel forward is the eval (HIP) path; call model.eval()")
-        if self.eng is None:
-            self.eng = model._engine_for(inputs_local, self._engine_cls)
-        eng = self.eng
+        eng = model._engine_for(inputs_local, self._engine_cls)   # a dict lookup; never cached here (load_state_dict /
+                                                                  # .to() / train() drop the model's packed weights)
         B = inputs_local.shape[0]
         N = model.agent_num
         with torch.no_grad():

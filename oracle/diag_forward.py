@@ -85,5 +85,61 @@ def main():
         agree, float((epred.argmax(1) == rpred.argmax(1)).float().mean())))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "stages"):
     main()
+
+
+# ---- per-stage attribution of the communication-graph error ------------------------------------
+STAGES = ("stem", "layer1", "layer2", "layer3", "layer4", "squeezer", "policy_conv1-2", "policy_conv3-5")
+
+
+def _stage_of(name):
+    """stage of a policy-path conv weight (query_key_net.*); None for the value trunk / decoder."""
+    if not name.startswith("query_key_net."):
+        return None
+    for li in (1, 2, 3, 4):
+        if ".layer%d." % li in name:
+            return "layer%d" % li
+    if name.endswith("feature_backbone.conv1.weight"):
+        return "stem"
+    if ".squeezer." in name:
+        return "squeezer"
+    if ".conv1." in name or ".conv2." in name:
+        return "policy_conv1-2"
+    return "policy_conv3-5"
+
+
+def stage_table(B=1, N=5, S=512, seed=1236):
+    """dP (max abs over the [B,N,N] graph) and relative key error when ONLY the conv operands of one stage of the policy
+    path are rounded to bf16 (everything else fp32), next to 'all stages' -- shows that no single stage, and in
+    particular not the 16x16-and-smaller tail, dominates: the error is spread over the trunk."""
+    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
+    sd = orc.to_torch(filler.fill_state_dict(orc.state_spec("MIMOcom", image_size=S)))
+    ptr2stage = {v.data_ptr(): _stage_of(k) for k, v in sd.items() if k.endswith("weight") and v.dim() == 4
+                 and ".feature_backbone.backbone_" not in k}
+    ex = {}
+    _, rprob, _, _ = orc.mimocom_forward(sd, x, N, training=False, MO_flag=True, inference="softmax", extras=ex)
+    real_conv = F.conv2d
+    rows = []
+    for sel in [(s,) for s in STAGES] + [STAGES[:5], STAGES[5:], STAGES]:
+        def conv(inp, w, b=None, **k):
+            if ptr2stage.get(w.data_ptr()) in sel:
+                return real_conv(bf16r(inp), bf16r(w), b, **k)
+            return real_conv(inp, w, b, **k)
+        try:
+            orc.F.conv2d = conv
+            eex = {}
+            _, eprob, _, _ = orc.mimocom_forward(sd, x, N, training=False, MO_flag=True, inference="softmax", extras=eex)
+        finally:
+            orc.F.conv2d = real_conv
+        rows.append(("+".join(sel) if len(sel) < 4 else ("trunk (stem..layer4)" if sel == STAGES[:5] else
+                     "squeezer+policy tail" if sel == STAGES[5:] else "ALL policy-path convs"),
+                     rel(eex["key_mat"], ex["key_mat"]), float((eprob - rprob).abs().max())))
+    print("bf16-rounded conv operands in ...      key rel-L2    max|dP|     (B=%d N=%d %dx%d seed %d)" % (B, N, S, S, seed))
+    for name, kr, dp in rows:
+        print("%-36s %10.2e %10.2e" % (name, kr, dp))
+    return rows
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stages":
+    stage_table(*[int(v) for v in sys.argv[2:6]])

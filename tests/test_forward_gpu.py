@@ -234,13 +234,25 @@ def test_hip_graph_replay_equals_eager_bit_for_bit():
     np.testing.assert_array_equal(keep[1].cpu().numpy(), snap.cpu().numpy())
 
 
-@pytest.mark.parametrize("arch,n,b,size,mode", [("MIMOcom", 8, 1, 512, "softmax"),        # cfg 3 shape (8 agents, 512^2)
-                                                ("MIMOcom", 2, 1, 1024, "softmax"),       # cfg 4 frame size (n_feat 16384)
-                                                ("MIMOcomWho", 5, 1, 512, "softmax"),     # cfg 5 model (who2com, query: False)
-                                                ("Single_agent", 1, 2, 512, None)])
-def test_baseline_config_shapes_match_oracle(arch, n, b, size, mode):
-    """The other BASELINE.json configs' shapes on one GPU vs the fp32 oracle (no golden vectors at these sizes:
-    the oracle itself is pinned by the 128^2 / 256^2 reference vectors)."""
+CFG_CASES = [
+    # BASELINE.json configs at their EXACT shapes on one GPU: name, arch, agents, batch, size, modes
+    ("cfg2", "MIMOcom", 5, 4, 512, ("softmax", "argmax_test", "activated")),      # [4,15,512,512], M = 20
+    ("cfg3", "MIMOcom", 8, 8, 512, ("softmax",)),                                 # 8 agents x B=8, M = 64
+    ("cfg4", "MIMOcom", 16, 2, 1024, ("softmax",)),                               # 16 agents x B=2 x 1024^2, M = 32
+    ("cfg5-bf16", "MIMOcomWho", 5, 4, 512, ("softmax", "activated")),             # who2com (query: False), bf16 trunk
+    ("single-512", "Single_agent", 1, 2, 512, None),
+]
+
+
+@pytest.mark.parametrize("name,arch,n,b,size,modes", CFG_CASES, ids=[c[0] for c in CFG_CASES])
+def test_baseline_config_shapes_match_oracle(name, arch, n, b, size, modes):
+    """Every BASELINE.json config at its exact input shape, through get_model(...).eval()(x), vs the fp32 oracle (no
+    golden vectors at these sizes: the oracle itself is pinned by the 128^2 / 256^2 reference vectors).  The seeds are
+    NOT conditioned like the committed fixtures, so (a) the tolerance is anchored on what ANY bf16-storage pipeline
+    loses on this input (oracle with conv operands / ReLU outputs rounded to bf16): the HIP path must stay within 2.5x
+    of that floor and never beyond 3x the fixture tolerances; (b) in the thresholded modes only the prediction rows
+    whose graph column is decided with margin (every |P - 0.2| >= 0.04, top-2 gap >= 0.04 in the oracle) are compared
+    -- a row whose coefficient sits on the threshold legitimately flips under 1e-2 of P error."""
     from oracle import diag_forward as diag
     has_query = arch != "MIMOcomWho"
     case = dict(arch=arch, agent_num=n, batch=b, size=size, model_over={} if has_query else {})
@@ -257,20 +269,43 @@ def test_baseline_config_shapes_match_oracle(arch, n, b, size, mode):
         assert (pred.argmax(1) == ref.argmax(1)).float().mean().item() >= ARGMAX_AGREE
         return
     x = torch.from_numpy(filler.synthetic_frames(b, n, size, size, 77))
-    pred, prob, action, _ = model(x.cuda(), training=False, MO_flag=True, inference=mode)
+    assert tuple(x.shape) == (b, 3 * n, size, size)
     fwd = orc.mimocom_forward if arch == "MIMOcom" else orc.mimocomwho_forward
-    ref, rprob, raction, _ = fwd(sd, x, n, training=False, MO_flag=True, inference=mode, has_query=has_query)
-    # these seeds are NOT conditioned like the committed fixtures: measure what ANY bf16-storage pipeline loses on
-    # this input (oracle with conv operands / ReLU outputs rounded to bf16) and require the HIP path to stay within
-    # 2.5x of that floor (and never worse than 3x the fixture tolerances)
-    (epred, eprob, _, _), _ = diag.emulated(sd, x, n, has_query=has_query, fwd=fwd)
-    p_floor = float((eprob - rprob).abs().max())
-    l_floor = _rel_l2(epred.numpy(), ref.numpy())
-    p_err = float((prob.cpu() - rprob).abs().max())
-    l_err = _rel_l2(pred.cpu().numpy(), ref.numpy())
-    assert pred.shape == ref.shape
-    assert p_err <= min(max(P_ATOL, 2.5 * p_floor), 3 * P_ATOL), (p_err, p_floor)
-    assert l_err <= min(max(REL_L2, 2.5 * l_floor), 3 * REL_L2), (l_err, l_floor)
-    agree_floor = (epred.argmax(1) == ref.argmax(1)).float().mean().item()
-    agree = (pred.cpu().argmax(1) == ref.argmax(1)).float().mean().item()
-    assert agree >= min(0.985, agree_floor - 0.01), (agree, agree_floor)
+    (epred, eprob, _, _), _ = diag.emulated(sd, x, n, has_query=has_query, fwd=fwd)         # softmax mode
+    xg = x.cuda()
+    for mode in modes:
+        pred, prob, action, nconn = model(xg, training=False, MO_flag=True, inference=mode)
+        pred, prob, action = pred.cpu(), prob.cpu(), action.cpu()
+        ref, rprob, raction, rconn = fwd(sd, x, n, training=False, MO_flag=True, inference=mode, has_query=has_query)
+        assert pred.shape == ref.shape == (n * b, 11, size, size) and prob.shape == (b, n, n)
+        p_floor = float((eprob - rprob).abs().max())
+        p_err = float((prob - rprob).abs().max())
+        assert p_err <= min(max(P_ATOL, 2.5 * p_floor), 3 * P_ATOL), (mode, p_err, p_floor)
+        # rows (q*b + sample) whose graph column is decided with margin
+        top2 = rprob.topk(2, dim=1)[0]                                                   # [b, 2, n]
+        safe = ((rprob - 0.2).abs().min(dim=1)[0] >= 0.04) & ((top2[:, 0] - top2[:, 1]) >= 0.04)   # [b, n_query]
+        if mode == "softmax":
+            safe = torch.ones_like(safe)
+        rows = torch.tensor([q * b + bb for q in range(n) for bb in range(b) if bool(safe[bb, q])], dtype=torch.long)
+        assert len(rows) >= (n * b) // 4, "seed leaves too few margin-safe graph columns to compare"
+        assert torch.equal(action[safe], raction[safe]), mode
+        if bool(safe.all()):
+            assert abs(float(nconn) - float(rconn)) < 1e-9
+        got, want = pred[rows].numpy(), ref[rows].numpy()
+        l_err = _rel_l2(got, want)
+        if mode == "softmax":
+            l_floor = _rel_l2(epred.numpy(), ref.numpy())
+            agree_floor = (epred.argmax(1) == ref.argmax(1)).float().mean().item()
+            assert l_err <= min(max(REL_L2, 2.5 * l_floor), 3 * REL_L2), (l_err, l_floor)
+        else:
+            agree_floor = 1.0
+            assert l_err <= (REL_L2_ACTIVATED if mode == "activated" else REL_L2), (mode, l_err)
+        agree = float((pred[rows].argmax(1) == ref[rows].argmax(1)).float().mean())
+        assert agree >= min(0.985 if mode != "activated" else ARGMAX_AGREE_ACTIVATED, agree_floor - 0.01), (mode, agree)
+        labels = filler.synthetic_labels(n * b, size, size, 77)
+        miou = orc.mean_iou(orc.confusion_matrix(labels[rows.numpy()], got.argmax(1)))
+        rmiou = orc.mean_iou(orc.confusion_matrix(labels[rows.numpy()], want.argmax(1)))
+        assert abs(miou - rmiou) <= MIOU_TOL
+        # the informative score (uniform random labels make the line above trivially true): mIoU of the HIP label map
+        # AGAINST the oracle's label map, i.e. per-class agreement
+        assert orc.mean_iou(orc.confusion_matrix(want.argmax(1), got.argmax(1))) >= 0.95

@@ -135,6 +135,73 @@ def test_engine_cache_invalidation_rules():
     m._engines[0] = object()
     m.float()
     assert not m._engines
+    # eval() -> eval() keeps the packed weights / captured graphs (the evaluator calls model.eval() every pass)
+    m.eval()
+    m._engines[0] = marker = object()
+    m.eval()
+    assert m._engines.get(0) is marker
+    m.train()
+    assert not m._engines
+
+
+def _replicate_like_data_parallel(module):
+    """What torch.nn.parallel.replicate() leaves on a replica (torch/nn/parallel/replicate.py), without needing GPUs:
+    shallow __dict__ copies, EMPTY _parameters, weights re-attached as plain tensor attributes."""
+    modules = list(module.modules())
+    index = {m: i for i, m in enumerate(modules)}
+    copies = [m._replicate_for_data_parallel() for m in modules]
+    for i, m in enumerate(modules):
+        for key, child in m._modules.items():
+            setattr(copies[i], key, None if child is None else copies[index[child]])
+        for key, prm in m._parameters.items():
+            if prm is None:
+                copies[i]._parameters[key] = None
+            else:
+                setattr(copies[i], key, prm.detach().clone())
+        for key, buf in m._buffers.items():
+            if buf is not None:
+                setattr(copies[i], key, buf.detach().clone())
+    return copies[0]
+
+
+@pytest.mark.parametrize("arch", ["MIMOcom", "Single_agent"])
+def test_engine_lookup_works_on_data_parallel_replicas(arch):
+    """train.py:177 wraps the model in nn.DataParallel; replicas have no registered parameters, so the engine lookup
+    must not go through .parameters().  The weight packing itself must also work from a replica."""
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import engine
+    from multiagentperception_amd._native import W2CError
+    m = get_model(_cfg(arch, n=2, size=128), 11).eval()
+    rep = _replicate_like_data_parallel(m)
+    assert list(rep.parameters()) == []                                    # the condition that used to raise StopIteration
+    assert rep._engines is m._engines                                      # per-device cache shared across replicas
+    x = torch.zeros(1, 6 if arch == "MIMOcom" else 3, 128, 128)
+    with pytest.raises(W2CError, match="no CPU fallback"):                 # reaches the device check, not StopIteration
+        rep(x, training=False, MO_flag=True, inference="softmax") if arch == "MIMOcom" else rep(x)
+    plan = engine.TrunkPlan([rep.u_encoder if arch == "MIMOcom" else rep.encoder])
+    ref = engine.TrunkPlan([m.u_encoder if arch == "MIMOcom" else m.encoder])
+    np.testing.assert_array_equal(plan.blocks[3][0].w.float().numpy(), ref.blocks[3][0].w.float().numpy())
+
+
+def test_head_plan_rejects_a_resolution_the_model_was_not_built_for():
+    """the reference fails in view(-1, n_feat) when the frames are not image_size; the engine must raise too,
+    not read fc.0 with a wrong channel count."""
+    from multiagentperception_amd import engine
+    from multiagentperception_amd._native import W2CError
+    from multiagentperception_amd.models import blocks
+    head = blocks.km_generator(out_size=1024, input_feat_sz=128 / 32)     # n_feat = 256 (1x1 policy map)
+    with pytest.raises(W2CError, match="image_size"):
+        engine.HeadPlan([head], hw=3)
+
+    class _Eng:
+        _heads = {}
+        _model_heads = (head, None)
+        wq = torch.zeros(1024, 32)
+        bq = torch.zeros(1024)
+        _head_plan = engine.CommEngine._head_plan
+    with pytest.raises(W2CError, match="image_size"):
+        _Eng()._head_plan(torch.zeros(2, 2, 2, 256))                      # a 256^2 frame through a 128^2 model
+    assert _Eng()._head_plan(torch.zeros(2, 1, 1, 256)).n_feat == 256
 
 
 def test_train_mode_stock_op_path_keeps_reference_return_tuple():

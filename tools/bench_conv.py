@@ -28,19 +28,10 @@ LAYERS = [
     ("dec1 256->32 @16 f32", 20, 16, 16, 256, 32, 3, 1, 1, False),
 ]
 VALID = {  # variant -> (BM, BN, BK)
-    0: (128, 128, 64), 1: (128, 128, 32), 2: (128, 128, 64), 3: (128, 64, 64), 4: (128, 64, 64), 5: (128, 64, 32),
-    6: (64, 64, 64), 7: (64, 64, 64), 8: (128, 32, 64), 9: (128, 32, 64), 10: (256, 128, 64), 11: (256, 128, 32),
-    12: (128, 128, 32), 13: (64, 64, 64), 14: (128, 64, 64), 15: (256, 64, 64),
-    20: (256, 128, 64), 21: (256, 128, 64), 22: (256, 64, 64), 23: (256, 128, 64), 24: (256, 64, 64), 25: (256, 64, 64),
-    26: (256, 128, 64),
-    38: (128, 64, 64), 39: (128, 64, 64), 50: (64, 64, 64), 51: (64, 128, 64),
-    35: (128, 128, 64), 36: (128, 64, 64), 37: (128, 128, 64),
-    30: (128, 128, 64), 31: (128, 64, 64), 32: (128, 128, 64), 33: (128, 64, 64), 34: (128, 64, 64),
+    0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
+    30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64),
 }
-PATCH_GEOM = {20: (8, 32), 21: (8, 32), 22: (8, 32), 23: (16, 16), 24: (16, 16), 25: (8, 32), 26: (16, 16),
-              38: (8, 16), 39: (8, 16), 50: (4, 16), 51: (4, 16),
-              35: (8, 16), 36: (8, 16), 37: (8, 16),
-              30: (8, 16), 31: (8, 16), 32: (4, 32), 33: (4, 32), 34: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16)}
 
 
 def main():

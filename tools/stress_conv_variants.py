@@ -20,9 +20,9 @@ def run(name, M,H,W,cin,cout,G,ref_v,variants,reps=60,stride=1,ks=3):
             if not torch.equal(y, first): bad+=1
         d = float((first.float()-ref.float()).abs().max())
         print("%-26s v%-3d: %d/%d runs differ from the first run; max|first-ref(v%d)| %.4f"%(name,v,bad,reps,ref_v,d))
-run("l1 64->64 @128 g2", 20,128,128,64,64,2, 3, [3,31,34,36,38,39,50])
-run("l2 128->128 @64 g2", 20,64,64,128,128,2, 0, [0,30,31,26,35,37,36,51])
-run("l3 256->256 @32 g2", 20,32,32,256,256,2, 0, [0,30,33])
-run("l4 512->512 @16 g2", 20,16,16,512,512,2, 0, [3,30,26])
-run("pol2 512->256 @16", 20,16,16,512,256,1, 6, [6,31])
+run("l1 64->64 @128 g2", 20,128,128,64,64,2, 3, [3,36,38,50])
+run("l2 128->128 @64 g2", 20,64,64,128,128,2, 0, [0,30,36])
+run("l3 256->256 @32 g2", 20,32,32,256,256,2, 0, [0,30,36])
+run("l4 512->512 @16 g2", 20,16,16,512,512,2, 0, [3,30,36])
+run("pol2 512->256 @16", 20,16,16,512,256,1, 6, [6,36])
 run("l2.0 s2", 20,128,128,64,128,2, 0, [0,3], stride=2)
