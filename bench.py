@@ -1,30 +1,45 @@
 #!/usr/bin/env python
 """bench.py -- When2com forward throughput on MI355X (the metric of BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one eval forward (`inference='softmax'`, the single-decode mode) of mrms-when2com on a
-synthetic AirSim-MAP-shaped batch already resident in HBM: per rank B=4 samples x 5 agents x
-512x512 (BASELINE.json configs[1]).  With N ranks the agents are sharded (5 per rank, 5N agents in
-one communication graph) and K/V are all-gathered over RCCL -- weak scaling.  `value` is
-agent-images/s over all ranks (image = one agent frame).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own ranks (re-executes itself under
+torch.distributed.run on 127.0.0.1), so `python bench.py --gpus 8` and the torchrun form are the same run.
+
+One step = one eval forward (`inference='softmax'`, the single-decode mode) on a synthetic AirSim-MAP-shaped batch already
+resident in HBM.  Workloads (BASELINE.json `configs`):
+  cfg2 (default)  mrms-when2com, 5 agents x B=4 x 512x512 PER GPU (N=1: exactly configs[1]); with N ranks the 5N agents
+                  form one communication graph -> weak scaling
+  cfg3            mrms-when2com, 8 agents x B=8 x 512x512 in total, agents sharded over the ranks (8 GPUs: 1 agent/GPU)
+                  -> strong scaling
+  cfg4            mrms-when2com, 16 agents x B=2 x 1024x1024 in total (8 GPUs: 2 agents/GPU) -> strong scaling
+  cfg5            mrms-who2com (MIMOcomWho, query: False), 5 agents x B=4 x 512x512 per GPU
+`value` is agent-images/s over all ranks (image = one agent frame).
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel w2c_conv_igemm_bf16 (MFMA bound): algorithmic FLOPs of all its
-                  launches in one forward / the sum of their HIP-event durations, vs 2.5 PFLOP/s
-                  dense bf16 (MI355X_MICROARCH.md).  Measured in a separate attribution pass after
-                  the timed region (events around every conv launch on the launch stream).
-  cpu_baseline -- the oracle (oracle/when2com_oracle.py, stock PyTorch CPU fp32 = the ops the
-                  reference bottoms out in; kind "port") timed on this host's cores on a bounded
-                  sample of the same workload (rank 0, N=1 only).
-  parity       -- HIP vs oracle on that same sample: logits rel-L2, argmax agreement, mIoU of both
-                  against the same synthetic labels.
+  roofline     -- the dominant kernel family w2c_conv_igemm_bf16 (MFMA bound): algorithmic FLOPs of all its launches in
+                  one forward / the sum of their HIP-event durations (events on the launch stream, attribution pass
+                  after the timed region), vs 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  `traffic` = HBM bytes per
+                  forward of the same launches from two rocprofv3 PMC passes (FETCH_SIZE x2 -- the gfx950 correction of
+                  MI355X_MICROARCH.md "HBM" -- and WRITE_SIZE, separate passes, --kernel-trace only) that this script
+                  runs on itself (N=1, rank 0; --no-pmc skips them, a failed pass leaves null).
+  cpu_baseline -- the oracle (oracle/when2com_oracle.py, stock PyTorch CPU fp32 = the ops the reference bottoms out
+                  in; kind "port") timed on this host's cores on the SAME batch (rank 0, N=1 only).
+  parity       -- HIP vs oracle on that batch: logits rel-L2, argmax agreement, per-class agreement (mIoU of the HIP
+                  label map against the oracle's label map).
+  comm         -- (N>1) RCCL rank count and the measured time of one step's collectives.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,27 +50,58 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md chip table
-GFLOP_PER_AGENT_IMAGE_512 = 42.919   # SURVEY.md section 8d (2*MAC, conv+linear)
+GFLOP_PER_AGENT_IMAGE_512 = {"MIMOcom": 42.919, "MIMOcomWho": 43.523}   # SURVEY.md section 8d (2*MAC, conv+linear)
+
+PRESETS = {
+    # name: arch, agents (per GPU when weak, total when strong), batch, size, scaling, has_query
+    "cfg2": dict(arch="MIMOcom", agents=5, batch=4, size=512, scaling="weak", query=True,
+                 label="mrms-when2com, 5 agents/GPU x B=4 x 512x512 (BASELINE configs[1])"),
+    "cfg3": dict(arch="MIMOcom", agents=8, batch=8, size=512, scaling="strong", query=True,
+                 label="mrms-when2com, 8 agents x B=8 x 512x512 total, agent-parallel (BASELINE configs[2])"),
+    "cfg4": dict(arch="MIMOcom", agents=16, batch=2, size=1024, scaling="strong", query=True,
+                 label="mrms-when2com, 16 agents x B=2 x 1024x1024 total, agent-parallel (BASELINE configs[3])"),
+    "cfg5": dict(arch="MIMOcomWho", agents=5, batch=4, size=512, scaling="weak", query=False,
+                 label="mrms-who2com (query: False), 5 agents/GPU x B=4 x 512x512 (BASELINE configs[4])"),
+}
 
 
-def build_cfg(agent_num, size):
-    return {"model": dict(arch="MIMOcom", agent_num=agent_num, shared_img_encoder="unified", attention="general",
-                          sparse=False, query=True, query_size=32, key_size=1024, enc_backbone="resnet_encoder",
+def build_cfg(arch, agent_num, size, query=True):
+    return {"model": dict(arch=arch, agent_num=agent_num, shared_img_encoder="unified", attention="general",
+                          sparse=False, query=query, query_size=32, key_size=1024, enc_backbone="resnet_encoder",
                           dec_backbone="simple_decoder", feat_squeezer=-1, feat_channel=512, multiple_output=True),
             "data": {"img_rows": size, "img_cols": size}}
 
 
-def cpu_baseline(x_sample, n_agents, size, labels):
-    """Oracle forward on the host cores; bounded sample (B=1 of the batch)."""
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(arch, x, n_agents, size, has_query):
+    """Oracle forward on the host cores, on the same batch the GPU path is timed on."""
     from oracle import filler
     from oracle import when2com_oracle as orc
-    sd = orc.to_torch(filler.fill_state_dict(orc.state_spec("MIMOcom", image_size=size)))
-    run = lambda: orc.mimocom_forward(sd, x_sample, n_agents, training=False, MO_flag=True, inference="softmax")  # noqa: E731
-    # thread count: stock PyTorch CPU convs stop scaling (and collapse, 40+ s/forward) long before a
-    # 256-core host is full, so give the baseline its best setting: try a few counts once, keep the fastest.
+    sd = orc.to_torch(filler.fill_state_dict(orc.state_spec(arch, image_size=size, has_query=has_query)))
+    fwd = orc.mimocom_forward if arch == "MIMOcom" else orc.mimocomwho_forward
+    run = lambda: fwd(sd, x, n_agents, training=False, MO_flag=True, inference="softmax", has_query=has_query)  # noqa: E731
+    # thread count: stock PyTorch CPU convs stop scaling (and collapse) long before a 256-core host is full, so give the
+    # baseline its best setting: try a few counts once, keep the fastest.
     ncpu = os.cpu_count() or 1
     best_t, threads = None, 1
-    for cand in sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128)}):
+    for cand in sorted({min(c, ncpu) for c in (16, 32, 64)}):
         torch.set_num_threads(cand)
         run()
         t0 = time.perf_counter()
@@ -63,22 +109,98 @@ def cpu_baseline(x_sample, n_agents, size, labels):
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best_t, threads = dt, cand
-        if dt > 8.0:
+        if dt > 10.0:
             break
     torch.set_num_threads(threads)
     times = []
-    t_end = time.perf_counter() + 15.0
+    t_end = time.perf_counter() + 12.0
     out = None
-    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 15):
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 12):
         t0 = time.perf_counter()
         out = run()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    imgs = x_sample.shape[0] * n_agents
-    miou = orc.mean_iou(orc.confusion_matrix(labels, out[0].max(1)[1].numpy()))
+    imgs = x.shape[0] * n_agents
     return dict(value=imgs / med, unit="agent-images/s", cores=threads, kind="port", host_cpus=ncpu,
-                sample="B=1 x %d agents x %dx%d, %d timed forwards, median %.3f s, torch CPU fp32, %d threads "
-                       "(fastest of 8/16/32/64/128)" % (n_agents, size, size, len(times), med, threads)), out, miou
+                sample="the timed batch itself: B=%d x %d agents x %dx%d, %d timed forwards, median %.3f s, torch CPU fp32, "
+                       "%d threads (fastest of 16/32/64)" % (x.shape[0], n_agents, size, size, len(times), med, threads)), out
+
+
+# ---- HBM traffic of the dominant kernel family from rocprofv3 PMC passes (this script profiles itself) --------------
+def _is_conv_kernel(name):
+    return ("conv_igemm_kernel" in name or "conv3x3_" in name or "splitk_finish_kernel" in name or "conv_mx" in name)
+
+
+def pmc_child(args, preset):
+    """Child of the PMC passes: `--pmc-child R` runs exactly R identical eager forwards and nothing else."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from multiagentperception_amd import synth as filler
+    from ptsemseg.models import get_model
+    B, n, S = preset["batch"], preset["agents"], preset["size"]
+    model = get_model(build_cfg(preset["arch"], n, S, preset["query"]), 11)
+    filler.apply_to_module(model)
+    model = model.to(dev).eval()
+    model.use_hip_graph = False
+    _apply_precision(model, args)
+    x = torch.from_numpy(filler.synthetic_frames(B, n, S, S, 1234 + 2)).to(dev)
+    for _ in range(args.pmc_child):
+        model(x, training=False, MO_flag=True, inference=args.mode)
+    torch.cuda.synchronize(dev)
+
+
+def pmc_traffic(args, reps=4, timeout=240):
+    """Two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md 'PMC slots') over a
+    child that runs `reps` eager forwards.  Returns (dict | None, note).  Counter unit KiB; FETCH_SIZE x2 on gfx950."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="w2c_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    sums, per_kernel = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", out, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", str(reps), "--config", args.config,
+                   "--mode", args.mode] + (["--fp8"] if args.fp8 else []) + (["--bf16"] if args.bf16 else [])
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:])
+            tot = 0.0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and _is_conv_kernel(row["Kernel_Name"]):
+                        v = float(row["Counter_Value"]) * 1024.0
+                        tot += v
+                        key = row["Kernel_Name"].split("(")[0][:64] + " grid=" + row["Grid_Size"]
+                        e = per_kernel.setdefault(key, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
+                        e[counter] += v
+                        if counter == "FETCH_SIZE":
+                            e["n"] += 1
+            sums[counter] = tot / reps
+    except Exception as e:                                   # a profiler problem must never take the bench line down
+        return None, "PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kern = []
+    for k, e in sorted(per_kernel.items(), key=lambda kv: -(2 * kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
+        n = max(e["n"], 1)
+        kern.append(dict(kernel=k, launches_per_step=round(n / reps, 2), read_MiB=round(2 * e["FETCH_SIZE"] / n / 2 ** 20, 2),
+                         write_MiB=round(e["WRITE_SIZE"] / n / 2 ** 20, 2)))
+    return dict(read_bytes=2.0 * sums["FETCH_SIZE"], write_bytes=sums["WRITE_SIZE"], per_kernel=kern[:12]), \
+        "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), %d eager forwards each; read = 2 x FETCH_SIZE " \
+        "(gfx950: the counter tallies 128-B requests at 64 B), write = WRITE_SIZE; conv-family launches only" % reps
+
+
+def _apply_precision(model, args):
+    """cfg5 names fp8 encoder convs; --bf16 forces the bf16 trunk, --fp8 forces fp8 on any config."""
+    want = (args.config == "cfg5" or args.fp8) and not args.bf16
+    if want and hasattr(model, "set_trunk_precision"):
+        model.set_trunk_precision("fp8")
+        return "fp8"
+    return "bf16"
 
 
 def main():
@@ -86,41 +208,71 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--agents-per-gpu", type=int, default=5)
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--config", default="cfg2", choices=sorted(PRESETS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--agents", type=int, default=None, help="agents per GPU (weak presets) / in total (strong presets)")
+    ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--mode", default="softmax", choices=["softmax", "argmax_test", "activated"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3, MX-scaled MFMA) trunk convs")
+    ap.add_argument("--bf16", action="store_true", help="force the bf16 trunk (cfg5 defaults to fp8)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: debugging only (several ranks on one GPU; RCCL refuses that)")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    preset = dict(PRESETS[args.config])
+    for k, v in (("batch", args.batch), ("agents", args.agents), ("size", args.size)):
+        if v is not None:
+            preset[k] = v
+    if args.pmc_child:
+        return pmc_child(args, preset)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the measured path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (world, ndev))
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from multiagentperception_amd import synth as filler     # deterministic weights / synthetic frames (same generator as the fixtures)
     from ptsemseg.models import get_model          # the reference's import path
     from multiagentperception_amd import ops
     from multiagentperception_amd.parallel import AgentParallelForward
 
-    B, n_loc, S = args.batch, args.agents_per_gpu, args.size
-    N = n_loc * world
-    model = get_model(build_cfg(N, S), 11)
+    arch, B, S = preset["arch"], preset["batch"], preset["size"]
+    if preset["scaling"] == "weak":
+        n_loc, N = preset["agents"], preset["agents"] * world
+    else:
+        N = preset["agents"]
+        if N % world:
+            raise SystemExit("%s has %d agents: --gpus must divide it" % (args.config, N))
+        n_loc = N // world
+    model = get_model(build_cfg(arch, N, S, preset["query"]), 11)
     filler.apply_to_module(model)
     model = model.to(dev).eval()
     model.use_hip_graph = not args.no_graph
-    frames = filler.synthetic_frames(B, n_loc, S, S, 1234 + 2 + rank)          # cfg 2 seed + rank
+    precision = _apply_precision(model, args)
+    if preset["scaling"] == "weak":
+        frames = filler.synthetic_frames(B, n_loc, S, S, 1234 + 2 + rank)          # cfg 2 seed + rank
+    else:
+        frames_all = filler.synthetic_frames(B, N, S, S, 1234 + 3)
+        frames = np.ascontiguousarray(frames_all[:, 3 * rank * n_loc:3 * (rank + 1) * n_loc])
     x = torch.from_numpy(frames).to(dev)
     fwd = AgentParallelForward(model)
 
@@ -160,66 +312,114 @@ def main():
     ops.set_conv_timer(None)
     model.use_hip_graph = not args.no_graph
     conv_ms, conv_fl, launches, per_shape = timer.summary()
+    conv_bytes = timer.algorithmic_bytes() / reps
     conv_ms /= reps
     conv_fl /= reps
     launches //= reps
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    flop_per_img = GFLOP_PER_AGENT_IMAGE_512 * (S / 512.0) ** 2
-    roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS,
-                    unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
-                    traffic_note="PMC FETCH_SIZE/WRITE_SIZE per launch are in profiles/r01_j_pmc_hbm_traffic.txt "
-                                 "(needs rocprofv3, cannot be read from inside bench.py): 1.0-1.1x the algorithmic bytes",
+    flop_per_img = GFLOP_PER_AGENT_IMAGE_512[arch] * (S / 512.0) ** 2
+    peak = PEAK_BF16_TFLOPS
+    layers = []
+    for key, (ms, fl, cnt) in sorted(per_shape.items(), key=lambda kv: -kv[1][0]):
+        layers.append(dict(rows=key[0], cin=key[1], cout=key[2], k=key[3], stride=key[4], groups=key[5],
+                           launches_per_step=cnt // reps, us_per_launch=round(1e3 * ms / cnt, 1),
+                           tflops=round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0))
+    roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16", achieved=round(achieved, 2), peak=peak,
+                    unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
                     launches_per_step=launches, kernel_ms_per_step=round(conv_ms, 4),
                     algorithmic_gflop_per_step=round(conv_fl / 1e9, 2),
+                    algorithmic_bytes_per_step=int(conv_bytes),
                     whole_forward_tflops=round(value * flop_per_img / 1e3, 2),
-                    whole_forward_frac=round(value * flop_per_img / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+                    whole_forward_frac=round(value * flop_per_img / 1e3 / (peak * world), 4),
+                    layers=layers[:12])
 
+    workload = "%s; eval forward, inference=%s" % (preset["label"], args.mode)
+    if any(v is not None for v in (args.batch, args.agents, args.size)):
+        workload = "%s %d agents x B=%d x %dx%d (overridden); eval forward, inference=%s" % (arch, N, B, S, S, args.mode)
     result = dict(metric="forward agent-images/sec, 5-agent 512x512 mrms-when2com", value=round(value, 2),
                   unit="agent-images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                  ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-                  dtype="bf16", data="synthetic",
-                  config=dict(workload="mrms-when2com MIMOcom forward (eval, inference=%s), %d agents/GPU x B=%d x %dx%d, "
-                                       "agent-parallel K/V all-gather" % (args.mode, n_loc, B, S, S),
-                              agents_total=N, global_batch=B, frames_per_s=round(B * args.steps / elapsed, 2),
+                  ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling=preset["scaling"], vs_baseline=None,
+                  dtype=precision, data="synthetic",
+                  config=dict(workload=workload, preset=args.config, agents_total=N, agents_per_gpu=n_loc, global_batch=B,
+                              frames_per_s=round(B * args.steps / elapsed, 2),
                               parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
-                              launch="hip-graph replay" if (model.use_hip_graph and world == 1) else "eager"),
+                              launch=("hip-graph replay" if world == 1 else "3 hip-graph segments + eager collectives")
+                              if model.use_hip_graph else "eager"),
                   roofline=roofline)
+
+    # ---- collectives of one step, timed alone (N > 1) ---------------------------------------------
+    if world > 1:
+        from multiagentperception_amd import parallel as par
+        eng = model._engine_for(x, fwd._engine_cls)
+        st = fwd._state(eng, x)
+        fence()
+        t0 = time.perf_counter()
+        n_it = 20
+        for _ in range(n_it):
+            w1 = par._gather_inplace(st.v_all, rank, n_loc * B, None)
+            w2 = par._gather_inplace(st.k_all, rank, n_loc * B, None)
+            par.exchange_wait(w1)
+            par.exchange_wait(w2)
+        torch.cuda.synchronize(dev)
+        comm_us = 1e6 * (time.perf_counter() - t0) / n_it
+        result["comm"] = dict(backend=("rccl" if args.backend == "nccl" else "gloo"), ranks=world,
+                              us_per_step_unoverlapped=round(comm_us, 1),
+                              v_shard_bytes=int(st.v_slot.numel() * 2), k_shard_bytes=int(st.k_slot.numel() * 4),
+                              note="all-gather of V (bf16, written in place by the squeezer) + projected keys; in the timed "
+                                   "step the V gather runs under the policy tail")
 
     # ---- evaluator fast path, reported beside the headline, never as `value` ---
     if world == 1:
         u8 = torch.from_numpy(filler.synthetic_frames_u8(B, n_loc, S, S, 1234 + 2 + rank)).to(dev)
+        gt = torch.from_numpy(filler.synthetic_labels(N * B, S, S, 1234 + 2)).to(torch.uint8).to(dev)
+        hist = torch.zeros(121, dtype=torch.int64, device=dev)
         for _ in range(args.warmup):
-            model.forward_labels(u8, inference=args.mode)
+            model.forward_confusion(u8, gt, hist, inference=args.mode)
+        hist.zero_()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            lab = model.forward_labels(u8, inference=args.mode)
+            model.forward_confusion(u8, gt, hist, inference=args.mode)
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
-        same = bool(torch.equal(lab[0].long(), out[0].max(1)[1]))
-        result["evaluator_path"] = dict(what="u8 RGB frames -> u8 label maps (loader transform + class argmax fused)",
+        lab = model.forward_labels(u8, inference=args.mode)
+        want = np.bincount((11 * gt.cpu().numpy().astype(np.int64) + out[0].max(1)[1].cpu().numpy()).reshape(-1), minlength=121)
+        result["evaluator_path"] = dict(what="u8 RGB frames + u8 labels -> 121 confusion-matrix counters on the device (loader "
+                                             "transform, class argmax and runningScore.update fused; no logits, no label map)",
                                         value=round(images_per_step * args.steps / el, 2), unit="agent-images/s",
                                         ms_per_step=round(1e3 * el / args.steps, 4),
-                                        labels_equal_argmax_of_headline_logits=same)
+                                        labels_equal_argmax_of_headline_logits=bool(torch.equal(lab[0].long(), out[0].max(1)[1])),
+                                        confusion_equals_host_bincount=bool((hist.cpu().numpy() == want * args.steps).all()))
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0, single GPU only) ---------------------
+    # ---- HBM traffic of the conv family from PMC counters (N=1, rank 0) ---------------------------
+    if rank == 0 and world == 1 and not args.no_pmc:
+        tr, note = pmc_traffic(args)
+        roofline["traffic_note"] = note
+        if tr is not None:
+            total = tr["read_bytes"] + tr["write_bytes"]
+            roofline["traffic"] = int(total)
+            roofline["traffic_read_bytes"] = int(tr["read_bytes"])
+            roofline["traffic_write_bytes"] = int(tr["write_bytes"])
+            roofline["traffic_over_algorithmic"] = round(total / conv_bytes, 3) if conv_bytes else None
+            roofline["traffic_per_kernel"] = tr["per_kernel"]
+    elif not args.no_pmc:
+        roofline["traffic_note"] = "PMC passes run at N=1 only"
+
+    # ---- CPU baseline + parity on the timed batch (rank 0, single GPU only) -----------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import when2com_oracle as orc
-        xs = torch.from_numpy(frames[:1])
-        labels = filler.synthetic_labels(N, S, S, 1234 + 2)
-        base, ref_out, ref_miou = cpu_baseline(xs, N, S, labels)
-        hip = model(xs.to(dev), training=False, MO_flag=True, inference="softmax")
-        hp = hip[0].cpu()
+        xs = torch.from_numpy(frames)
+        base, ref_out = cpu_baseline(arch, xs, N, S, preset["query"])
+        hp = out[0].cpu()
         rp = ref_out[0]
-        hip_miou = orc.mean_iou(orc.confusion_matrix(labels, hp.max(1)[1].numpy()))
-        agree_labels = rp.max(1)[1].numpy()
+        hl, rl = hp.max(1)[1].numpy(), rp.max(1)[1].numpy()
         result["cpu_baseline"] = base
         result["parity"] = dict(
+            on="the timed batch (same M as the timed run)",
             logits_rel_l2=float(np.linalg.norm(hp.numpy() - rp.numpy()) / np.linalg.norm(rp.numpy())),
-            argmax_agreement=float((hp.argmax(1) == rp.argmax(1)).float().mean()),
-            prob_max_abs=float((hip[1].cpu() - ref_out[1]).abs().max()),
-            miou_vs_synthetic_labels=dict(hip=hip_miou, oracle=ref_miou, delta=hip_miou - ref_miou),
-            miou_hip_vs_oracle_argmax=orc.mean_iou(orc.confusion_matrix(agree_labels, hp.max(1)[1].numpy())))
+            argmax_agreement=float((hl == rl).mean()),
+            prob_max_abs=float((out[1].cpu() - ref_out[1]).abs().max()),
+            miou_hip_vs_oracle_argmax=orc.mean_iou(orc.confusion_matrix(rl, hl)))
         result["speedup_vs_cpu"] = round(value / base["value"], 1)
     if rank == 0:
         print(json.dumps(result))

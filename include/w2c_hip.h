@@ -85,6 +85,10 @@ int w2c_maxpool3x3s2(const uint16_t* x, int M, int H, int W, int C, uint16_t* y,
  * residual : bf16, same geometry as y (nullable)
  * y        : bf16 (y_is_f32=0) or f32 (y_is_f32=1) NHWC, pixel stride
  *            y_cstride; group g writes channels [g*Cout, (g+1)*Cout)
+ * y_group_stride : element offset between the groups' output slabs (0 = Cout: side by side in one NHWC tensor).
+ *            Any multiple of 8 is allowed, so group 0 can be written contiguously (y_cstride = Cout) straight into
+ *            another buffer -- the agent-parallel path lets the u_encoder squeezer write V into its rank's slot of the
+ *            all-gather buffer while the policy encoder's map goes to a private one.  `residual` uses the same geometry.
  * zero_page: >= 256 bytes of zeros (source for padded taps)
  * Cin multiple of 64; Cout multiple of 32.  x and w are addressed through 32-bit buffer descriptors: an x tensor of
  * >= 2 GiB (M*H*W*x_cstride*2 bytes) or >= 2^29 output pixels returns W2C_E_ARG -- split M (results do not depend on
@@ -94,7 +98,7 @@ int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_c
                         const float* scale, const float* shift,
                         const uint16_t* residual, int relu,
                         void* y, int y_cstride, int y_is_f32,
-                        const void* zero_page, w2c_stream_t stream);
+                        const void* zero_page, long long y_group_stride, w2c_stream_t stream);
 
 /* Same contract, with the tile/pipeline variant forced (index into the table in csrc/conv_igemm.hip).
  * For tuning (tools/bench_conv.py) and tests.  Every variant walks K as (64-channel chunk, tap) and issues the same
@@ -106,7 +110,7 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
                                 const float* scale, const float* shift,
                                 const uint16_t* residual, int relu,
                                 void* y, int y_cstride, int y_is_f32,
-                                const void* zero_page, int variant, w2c_stream_t stream);
+                                const void* zero_page, int variant, long long y_group_stride, w2c_stream_t stream);
 
 /* Split-K form of K2 for the tail layers (policy_net4 conv3..5 agent.py:128-132, simple_decoder's last conv
  * backbone.py:152): few output tiles under a long weight-streaming K loop.  `ksplit` workgroups share a tile, each
@@ -120,7 +124,7 @@ int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W, int Cin, 
                                const uint16_t* residual, int relu,
                                void* y, int y_cstride, int y_is_f32,
                                const void* zero_page, int ksplit,
-                               void* workspace, long long workspace_bytes, w2c_stream_t stream);
+                               void* workspace, long long workspace_bytes, long long y_group_stride, w2c_stream_t stream);
 /* bytes of workspace the call above needs (0: the layer is not split; -1: invalid shape). */
 long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,
                                           int groups, int ksplit);
@@ -203,6 +207,20 @@ int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstri
  * (identical arithmetic to w2c_upsample_bilinear32, lowest index on ties); the f32 logits are never written. */
 int w2c_upsample32_argmax(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                           uint8_t* labels, w2c_stream_t stream);
+
+/* ---- SURVEY 8f row 4 (output side, second half): the evaluator's confusion matrix on the device.
+ * runningScore._fast_hist (metrics.py:99-108): hist[n*gt + pred] += 1 over the pixels with 0 <= gt < n.
+ * w2c_upsample32_argmax_confusion = w2c_upsample32_argmax + that histogram in one launch: neither the logits nor
+ * (when labels == NULL) the label map are written; the evaluator reads n*n int64 counters per validation pass.
+ * gt   : ground-truth labels [M, 32h, 32w], u8 (gt_is_i64=0; 4-byte aligned) or int64 (gt_is_i64=1) as the loader
+ *        yields them; values outside [0, n) are ignored (the reference's mask)
+ * hist : int64 [n*n], ACCUMULATED into (zero it once per evaluation); n_classes <= 64.  Exact (integer atomics). */
+int w2c_upsample32_argmax_confusion(const float* low, int M, int h, int w, int low_cstride, int n_classes,
+                                    const void* gt, int gt_is_i64, uint8_t* labels, long long* hist,
+                                    w2c_stream_t stream);
+/* The same histogram for label maps that already exist: pred u8 [n_pixels], gt u8 or int64 [n_pixels]. */
+int w2c_confusion_matrix(const void* gt, int gt_is_i64, const uint8_t* pred, long long n_pixels, int n_classes,
+                         long long* hist, w2c_stream_t stream);
 
 /* ---- helpers at the boundary ---- */
 /* f32 NCHW [M,C,H,W] -> bf16 NHWC [M,H,W,cstride] (channels [0,C)); used by tests and the

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libw2c_hip.so")
 
 _c = ctypes
-_vp, _i, _f = _c.c_void_p, _c.c_int, _c.c_float
+_vp, _i, _f, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong
 
 # symbol -> argtypes (restype is int unless noted); mirrors include/w2c_hip.h
 SIGNATURES = {
@@ -25,11 +25,11 @@ SIGNATURES = {
     "w2c_stem_u8_conv7x7_bn_relu_maxpool": [_vp, _c.c_double, _c.c_double, _c.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _i,
                                             _vp, _vp],
     "w2c_maxpool3x3s2": [_vp, _i, _i, _i, _i, _vp, _vp],
-    "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
+    "w2c_conv_igemm_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _ll, _vp],
     "w2c_conv_igemm_bf16_variant": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
-                                    _vp],
+                                    _ll, _vp],
     "w2c_conv_igemm_bf16_splitk": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
-                                   _vp, _c.c_longlong, _vp],
+                                   _vp, _ll, _ll, _vp],
     "w2c_conv_splitk_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_debug_conv_timeline": [_vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
@@ -40,6 +40,8 @@ SIGNATURES = {
     "w2c_fuse_values": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample32_argmax": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "w2c_upsample32_argmax_confusion": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "w2c_confusion_matrix": [_vp, _i, _vp, _ll, _i, _vp, _vp],
     "w2c_nchw_f32_to_nhwc_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_nhwc_bf16_to_nchw_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
 }

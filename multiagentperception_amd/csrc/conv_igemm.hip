@@ -52,6 +52,7 @@ struct ConvArgs {
     unsigned long long* dbg;   // optional timeline buffer (tools/conv_timeline.py): 4 x u64 per workgroup, else null
     float* ws;                 // split-K: f32 partial tiles [group][tile][split][BM][BN]
     int n_split;
+    long long ygs;             // element offset between the groups' output (and residual) slabs; Cout = side by side
 };
 
 __device__ __forceinline__ void dbg_stamp(const ConvArgs& p, int slot) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         const int r = idx / CG, cg = idx - r * CG;
         const int gr = m0 + r;
         e_ok[ps] = gr < p.rows;
-        e_off[ps] = (size_t)(e_ok[ps] ? gr : 0) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
+        e_off[ps] = (size_t)(e_ok[ps] ? gr : 0) * p.ycs + (size_t)g * p.ygs + n0 + cg * 8;
     }
     if (p.res && !SPLITK) {
 #pragma unroll
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         const int idx = ps * NT + tid;
         const int r = idx / CG, cg = idx - r * CG;
         const int oy = y0 + r / TW, ox = x0 + r % TW;
-        e_off[ps] = (((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.Cout + n0 + cg * 8;
+        e_off[ps] = (((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.ygs + n0 + cg * 8;
     }
     if (p.res) {                                   // all residual loads in flight together, under the LDS staging
 #pragma unroll
@@ -980,7 +981,7 @@ int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
 }
 
 int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.ks != 3 || a.stride != 1 || a.Cin != 64 || a.Cout != 64 || a.H % 4 != 0 || a.W % 16 != 0) return W2C_E_ARG;
+    if (a.ks != 3 || a.stride != 1 || a.Cin != 64 || a.Cout != 64 || a.H % 4 != 0 || a.W % 16 != 0 || a.ygs != 64) return W2C_E_ARG;
     if ((size_t)a.M * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.M * a.H * a.W * a.ycs * 2 >= (1ull << 31)) return W2C_E_ARG;
     return a.res ? launch_regw<true>(a, groups, s) : launch_regw<false>(a, groups, s);
 }
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
     v0 = v0 * *reinterpret_cast<const f32x4_t*>(p.scale + ch) + *reinterpret_cast<const f32x4_t*>(p.shift + ch);
     v1 = v1 * *reinterpret_cast<const f32x4_t*>(p.scale + ch + 4) + *reinterpret_cast<const f32x4_t*>(p.shift + ch + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const size_t off = (size_t)gr * p.ycs + ch;
+    const size_t off = (size_t)gr * p.ycs + (size_t)g * p.ygs + tn * BN + cg * 8;
     if (p.res) {
         const uint4 rr = *reinterpret_cast<const uint4*>(p.res + off);
         const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -1178,7 +1179,7 @@ int pick_variant(const ConvArgs& a, int groups) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
         // layer1 at full size: weights stationary in registers (v50) once every wave of the chip gets >= 4 tiles
         // (its 7 us weight prologue is per launch); smaller problems stay on the ring kernel
-        if (a.Cin == 64 && Cout == 64 && a.H % 4 == 0 && !a.y_f32 && (long)a.M * (a.H / 4) * (a.W / 16) * groups >= 4096 &&
+        if (a.Cin == 64 && Cout == 64 && a.ygs == 64 && a.H % 4 == 0 && !a.y_f32 && (long)a.M * (a.H / 4) * (a.W / 16) * groups >= 4096 &&
             (size_t)a.M * a.H * a.W * a.xcs * 2 < (1ull << 31) && (size_t)a.M * a.H * a.W * a.ycs * 2 < (1ull << 31))
             return 50;
         if (a.Cin == 64 && Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 38;
@@ -1194,13 +1195,14 @@ int pick_variant(const ConvArgs& a, int groups) {
 int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
               const uint16_t* w, int Cout, int ksize, int stride, int groups,
               const float* scale, const float* shift, const uint16_t* residual, int relu,
-              void* y, int y_cstride, int y_is_f32, const void* zero_page) {
+              void* y, int y_cstride, int y_is_f32, const void* zero_page, long long y_group_stride) {
     if (!x || !w || !scale || !shift || !y || !zero_page) return W2C_E_ARG;
     if (M <= 0 || H <= 0 || W <= 0 || groups <= 0) return W2C_E_ARG;
     if (Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 32) != 0) return W2C_E_ARG;
     if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return W2C_E_ARG;
-    if (x_cstride < groups * Cin || y_cstride < groups * Cout) return W2C_E_ARG;
-    if ((x_cstride % 8) != 0 || (y_cstride % 8) != 0) return W2C_E_ARG;   // 16-byte vector access
+    if (y_group_stride == 0) y_group_stride = Cout;
+    if (x_cstride < groups * Cin || y_cstride < (y_group_stride == Cout ? groups : 1) * Cout) return W2C_E_ARG;
+    if ((x_cstride % 8) != 0 || (y_cstride % 8) != 0 || (y_group_stride % 8) != 0) return W2C_E_ARG;   // 16-byte vector access
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.zeros = reinterpret_cast<const uint16_t*>(zero_page);
     a.M = M; a.H = H; a.W = W; a.Cin = Cin; a.xcs = x_cstride;
@@ -1218,6 +1220,7 @@ int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int 
     a.dbg = nullptr;
     a.ws = nullptr;
     a.n_split = 1;
+    a.ygs = y_group_stride;
     return W2C_OK;
 }
 
@@ -1228,11 +1231,11 @@ extern "C" int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int C
                                    const float* scale, const float* shift,
                                    const uint16_t* residual, int relu,
                                    void* y, int y_cstride, int y_is_f32,
-                                   const void* zero_page, w2c_stream_t stream) {
+                                   const void* zero_page, long long y_group_stride, w2c_stream_t stream) {
     w2c_clear_error();
     ConvArgs a;
     int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
-                       y, y_cstride, y_is_f32, zero_page);
+                       y, y_cstride, y_is_f32, zero_page, y_group_stride);
     if (rc != W2C_OK) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return launch_variant(pick_variant(a, groups), a, groups, s);
@@ -1259,11 +1262,11 @@ extern "C" int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W
                                           const uint16_t* residual, int relu,
                                           void* y, int y_cstride, int y_is_f32,
                                           const void* zero_page, int ksplit,
-                                          void* workspace, long long workspace_bytes, w2c_stream_t stream) {
+                                          void* workspace, long long workspace_bytes, long long y_group_stride, w2c_stream_t stream) {
     w2c_clear_error();
     ConvArgs a;
     int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
-                       y, y_cstride, y_is_f32, zero_page);
+                       y, y_cstride, y_is_f32, zero_page, y_group_stride);
     if (rc != W2C_OK) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const SplitPlan sp = plan_splitk(a, groups, ksplit);
@@ -1288,11 +1291,11 @@ extern "C" int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int 
                                            const float* scale, const float* shift,
                                            const uint16_t* residual, int relu,
                                            void* y, int y_cstride, int y_is_f32,
-                                           const void* zero_page, int variant, w2c_stream_t stream) {
+                                           const void* zero_page, int variant, long long y_group_stride, w2c_stream_t stream) {
     w2c_clear_error();
     ConvArgs a;
     int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
-                       y, y_cstride, y_is_f32, zero_page);
+                       y, y_cstride, y_is_f32, zero_page, y_group_stride);
     if (rc != W2C_OK) return rc;
     a.dbg = g_dbg_next;
     g_dbg_next = nullptr;

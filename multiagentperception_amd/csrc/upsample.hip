@@ -57,10 +57,21 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
 // logits (231 MB at cfg 2) are never written -- only one u8 label per pixel (5 MB).  Same source-index and lerp
 // arithmetic as upsample32_kernel, so labels == argmax over classes of its output, bit for bit; ties keep the
 // lowest class index.  Workgroup = (32-row band, image): the image's whole low-res logit block sits in LDS.
+//
+// CONF: the evaluator's confusion matrix (runningScore._fast_hist, metrics.py:99-108: bincount(n*gt + pred) over the
+// pixels with 0 <= gt < n) fused behind the argmax -- each workgroup histograms its 32-row band in LDS (a wave whose 64
+// lanes all hit one bin, the common case inside a segment, adds 64 with one atomic) and flushes its non-zero bins
+// with one 64-bit global atomic each.  Integer atomics: the result is exact and order-independent.
+template <bool CONF, bool GT64>
 __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
-                                                                uint8_t* __restrict__ labels) {
+                                                                uint8_t* __restrict__ labels, const void* __restrict__ gt,
+                                                                unsigned long long* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* blk = reinterpret_cast<float*>(smem);       // [ncls][h][w]
+    unsigned* lh = reinterpret_cast<unsigned*>(smem + (size_t)ncls * h * w * 4);      // CONF: [ncls*ncls] band histogram
+    if (CONF) {
+        for (int i = threadIdx.x; i < ncls * ncls; i += 256) lh[i] = 0;
+    }
     const int H = h * 32, W = w * 32;
     const int band = blockIdx.x, m = blockIdx.y;
     for (int i = threadIdx.x; i < ncls * h * w; i += 256) {
@@ -104,8 +115,57 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
             }
         }
         const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-        *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W + gx * 4) = packed;
+        if (labels) *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W + gx * 4) = packed;
+        if (CONF) {
+            const size_t pix = ((size_t)m * H + (size_t)band * 32 + ry) * W + gx * 4;
+            long long g4[4];
+            if (GT64) {
+                const long long* gp = reinterpret_cast<const long long*>(gt) + pix;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g4[e] = gp[e];
+            } else {
+                const uint32_t gw = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(gt) + pix);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g4[e] = (gw >> (8 * e)) & 0xFF;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = g4[e] >= 0 && g4[e] < ncls;
+                const int bin = ok ? (int)g4[e] * ncls + bi[e] : -1;
+                const int first = __builtin_amdgcn_readfirstlane(bin);
+                if (__builtin_amdgcn_ballot_w64(bin == first) == __builtin_amdgcn_ballot_w64(true)) {
+                    // the whole wave (its active lanes) in one bin: one atomic for all of them
+                    if (first >= 0 && (int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                        atomicAdd(&lh[first], (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+                } else if (ok) {
+                    atomicAdd(&lh[bin], 1u);
+                }
+            }
+        }
     }
+    if (CONF) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncls * ncls; i += 256)
+            if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+    }
+}
+
+// Standalone form of the same histogram for label maps that already exist (u8 predictions): hist[n*gt + pred] += 1.
+template <bool GT64>
+__global__ __launch_bounds__(256) void confusion_kernel(const void* __restrict__ gt, const uint8_t* __restrict__ pred, size_t n,
+                                                        int ncls, unsigned long long* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* lh = reinterpret_cast<unsigned*>(smem);
+    for (int i = threadIdx.x; i < ncls * ncls; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (size_t)gridDim.x * 256) {
+        const long long g = GT64 ? reinterpret_cast<const long long*>(gt)[id] : (long long)reinterpret_cast<const uint8_t*>(gt)[id];
+        const int pr = pred[id];
+        if (g >= 0 && g < ncls && pr < ncls) atomicAdd(&lh[(int)g * ncls + pr], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncls * ncls; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int M, int C, int HW,
@@ -156,8 +216,43 @@ extern "C" int w2c_upsample32_argmax(const float* low, int M, int h, int w, int 
         return W2C_E_ARG;
     const size_t lds = (size_t)n_classes * h * w * 4;
     if (lds > 64 * 1024) return W2C_E_ARG;
-    hipLaunchKernelGGL(upsample32_argmax_kernel, dim3(h, M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                       low, h, w, low_cstride, n_classes, labels);
+    hipLaunchKernelGGL((upsample32_argmax_kernel<false, false>), dim3(h, M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       low, h, w, low_cstride, n_classes, labels, nullptr, nullptr);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_upsample32_argmax_confusion(const float* low, int M, int h, int w, int low_cstride, int n_classes,
+                                               const void* gt, int gt_is_i64, uint8_t* labels, long long* hist,
+                                               w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!low || !gt || !hist || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || n_classes > 64 || low_cstride < n_classes)
+        return W2C_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(gt) & (gt_is_i64 ? 7 : 3)) || (reinterpret_cast<uintptr_t>(hist) & 7)) return W2C_E_ARG;
+    const size_t lds = (size_t)n_classes * h * w * 4 + (size_t)n_classes * n_classes * 4;
+    if (lds > 64 * 1024) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned long long* hp = reinterpret_cast<unsigned long long*>(hist);
+    if (gt_is_i64)
+        hipLaunchKernelGGL((upsample32_argmax_kernel<true, true>), dim3(h, M), dim3(256), lds, s, low, h, w, low_cstride,
+                           n_classes, labels, gt, hp);
+    else
+        hipLaunchKernelGGL((upsample32_argmax_kernel<true, false>), dim3(h, M), dim3(256), lds, s, low, h, w, low_cstride,
+                           n_classes, labels, gt, hp);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_confusion_matrix(const void* gt, int gt_is_i64, const uint8_t* pred, long long n_pixels, int n_classes,
+                                    long long* hist, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!gt || !pred || !hist || n_pixels <= 0 || n_classes <= 0 || n_classes > 64) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned long long* hp = reinterpret_cast<unsigned long long*>(hist);
+    const size_t lds = (size_t)n_classes * n_classes * 4;
+    const unsigned grid = (unsigned)(((size_t)n_pixels + 256 * 16 - 1) / (256 * 16) > 2048 ? 2048 : ((size_t)n_pixels + 256 * 16 - 1) / (256 * 16));
+    if (gt_is_i64)
+        hipLaunchKernelGGL((confusion_kernel<true>), dim3(grid ? grid : 1), dim3(256), lds, s, gt, pred, (size_t)n_pixels, n_classes, hp);
+    else
+        hipLaunchKernelGGL((confusion_kernel<false>), dim3(grid ? grid : 1), dim3(256), lds, s, gt, pred, (size_t)n_pixels, n_classes, hp);
     return w2c_launch_status();
 }
 

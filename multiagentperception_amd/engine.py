@@ -76,11 +76,11 @@ class ConvPlan:
         self.scale = torch.cat(scs).contiguous()
         self.shift = torch.cat(shs).contiguous()
 
-    def run(self, x, x_ch_off=0, residual=None, out_f32=False):
+    def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None):
         # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
                               self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,
-                              ksplit=None if os.environ.get('W2C_NO_SPLITK') else 0)
+                              ksplit=None if os.environ.get('W2C_NO_SPLITK') else 0, out_groups=out_groups)
 
 
 class TrunkPlan:
@@ -122,13 +122,15 @@ class TrunkPlan:
             return ops.stem_u8_conv7x7_bn_relu_maxpool(x, self.stem_w, self.stem_scale, self.stem_shift, out=out)
         return ops.stem_conv7x7_bn_relu_maxpool(x, n_agents, self.stem_w, self.stem_scale, self.stem_shift, out=out)
 
-    def after_stem(self, p):
-        """layer1..4 + squeezers on the pooled stem output -> bf16 NHWC [N*B, H/32, W/32, G*feat]."""
+    def after_stem(self, p, squeezer_out=None):
+        """layer1..4 + squeezers on the pooled stem output -> bf16 NHWC [N*B, H/32, W/32, G*feat]; with
+        squeezer_out = one [N*B, H/32, W/32, feat] tensor per trunk, each squeezer writes its own (the agent-parallel
+        path: V lands in the rank's slot of the all-gather buffer) and the list is returned."""
         for c1, c2, ds in self.blocks:
             t = c1.run(p)
             idt = p if ds is None else ds.run(p)
             p = c2.run(t, residual=idt)
-        return self.squeezer.run(p)
+        return self.squeezer.run(p, out_groups=squeezer_out)
 
     def run(self, x, n_agents):
         """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/32, W/32, G*feat] (squeezer outputs side by side)."""
@@ -170,7 +172,8 @@ class HeadPlan:
         self.b0 = torch.cat(b0s).contiguous()
         self.n_feat = n_feat
 
-    def run(self, qk_map):
+    def run(self, qk_map, outs=None):
+        """-> [key-head output, query-head output]; outs = preallocated (key, query) outputs for the two-head form."""
         M = qk_map.shape[0]
         if qk_map.shape[1] * qk_map.shape[2] * qk_map.shape[3] != self.n_feat:
             raise ops.W2CError("head: policy map %s does not flatten to fc.0's %d input features (input resolution differs "
@@ -178,12 +181,17 @@ class HeadPlan:
         h0 = ops.linear(qk_map, self.w0, self.b0, relu=True, x_stride=self.n_feat, rows=M)     # [M, 256*nheads]
         if len(self.tails) == 2 and self.tails[0][0] == self.tails[1][0]:      # key + query heads: one launch
             (k1, wa1, ba1, wa2, ba2), (_, wb1, bb1, wb2, bb2) = self.tails
-            return list(ops.head_tail2(h0, k1, (0, wa1, ba1, wa2, ba2), (k1, wb1, bb1, wb2, bb2)))
-        outs, col = [], 0
-        for k1, w1t, b1, w2t, b2 in self.tails:
-            outs.append(ops.head_tail(h0, col, k1, w1t, b1, w2t, b2))
+            oa, ob = outs if outs is not None else (None, None)
+            return list(ops.head_tail2(h0, k1, (0, wa1, ba1, wa2, ba2), (k1, wb1, bb1, wb2, bb2), out_a=oa, out_b=ob))
+        res, col = [], 0
+        for i, (k1, w1t, b1, w2t, b2) in enumerate(self.tails):
+            r = ops.head_tail(h0, col, k1, w1t, b1, w2t, b2)
+            if outs is not None and outs[i] is not None:
+                outs[i].copy_(r)
+                r = outs[i]
+            res.append(r)
             col += k1
-        return outs
+        return res
 
 
 class DecoderPlan:
@@ -236,15 +244,16 @@ class CommEngine:
             self._heads[hw] = plan
         return plan
 
-    def policy_tail(self, sq):
-        """policy_net4 conv1..5 + key/query heads on the policy-encoder half of `sq` (agent.py:137-141,
-        1126-1129) -> PROJECTED keys tproj f32 [n*B,Dq+1] (the attention's Linear(query) folded into the key
-        head, see HeadPlan), queries f32 [n*B,Dq] or None."""
-        y = self.policy[0].run(sq, x_ch_off=self.feat)
+    def policy_tail(self, sq, ch_off=None, outs=None):
+        """policy_net4 conv1..5 + key/query heads on the policy-encoder map -- channels [ch_off, ch_off+512) of `sq`,
+        by default its second half (agent.py:137-141, 1126-1129) -> PROJECTED keys tproj f32 [n*B,Dq+1] (the
+        attention's Linear(query) folded into the key head, see HeadPlan), queries f32 [n*B,Dq] or None.
+        outs = preallocated (tproj, queries)."""
+        y = self.policy[0].run(sq, x_ch_off=self.feat if ch_off is None else ch_off)
         for c in self.policy[1:]:
             y = c.run(y)
-        outs = self._head_plan(y).run(y)
-        return outs[0], (outs[1] if len(outs) > 1 else None)
+        res = self._head_plan(y).run(y, outs=outs)
+        return res[0], (res[1] if len(res) > 1 else None)
 
     def encode(self, x, n_agents):
         """-> sq (bf16 NHWC [n*B,h,w,1024]: V in [0,512), policy-encoder map in [512,1024)),
@@ -266,11 +275,19 @@ class CommEngine:
         return ops.upsample_bilinear32(low, self.n_classes), prob, action, nnz, low
 
     # ---- whole single-GPU forward, optionally replayed from a captured HIP graph ------------------
-    def forward_local(self, x, B, N, mode, use_graph=False, labels=False):
+    def forward_local(self, x, B, N, mode, use_graph=False, labels=False, confusion=None):
         """-> pred f32 [N*B,n_cls,H,W] (fresh tensor; or u8 class labels [N*B,H,W] when labels=True: the
-        evaluator's argmax fused into the upsample), prob [B,N,N], action [B,N], nnz [B]."""
-        finish = (lambda low: ops.upsample32_argmax(low, self.n_classes)) if labels else \
-                 (lambda low: ops.upsample_bilinear32(low, self.n_classes))
+        evaluator's argmax fused into the upsample), prob [B,N,N], action [B,N], nnz [B].
+        confusion = (gt labels u8|i64 [N*B,H,W], hist i64 [n_cls^2]): the evaluator's confusion matrix is accumulated
+        into hist by the same launch (metrics.py:99-108); the first return value is then the label map if labels=True,
+        else None."""
+        if confusion is not None:
+            finish = lambda low: ops.upsample32_argmax_confusion(low, self.n_classes, confusion[0], confusion[1],  # noqa: E731
+                                                                 want_labels=labels)
+        elif labels:
+            finish = lambda low: ops.upsample32_argmax(low, self.n_classes)             # noqa: E731
+        else:
+            finish = lambda low: ops.upsample_bilinear32(low, self.n_classes)           # noqa: E731
         if not use_graph:
             sq, keys, querys = self.encode(x, N)
             low, prob, action, nnz = self.graph_and_low(sq, keys, querys, B, N, 0, N, mode)

@@ -164,6 +164,28 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
         num_connect = self.agent_num - 1 if inference == "softmax" else int(nnz.sum().item()) / (self.agent_num * B)
         return labels, prob, action, num_connect
 
+    def forward_confusion(self, inputs, gt_labels, hist, MO_flag=True, inference="activated", want_labels=False):
+        """Evaluator fast path, second half (not part of the reference API): forward_labels
+        plus the evaluator's confusion matrix (runningScore.update, metrics.py:99-108) accumulated ON THE DEVICE into
+        `hist` (int64 [n_classes^2], zeroed by the caller once per validation pass) -- per step nothing but the labels
+        goes in and nothing comes back; the evaluator reads n^2 counters at the end.  gt_labels: u8 or int64
+        [N*B, H, W] device tensor, agent-major (torch.cat(labels_list, 0), trainer.py:795).
+        Returns (labels u8 or None, prob, action, num_connect)."""
+        if self.training:
+            raise W2CError("forward_confusion is an eval-only (HIP) path; call model.eval()")
+        if not MO_flag:
+            raise W2CError("MO_flag=False is not supported (see forward)")
+        if inference not in _INFERENCE_MODES:
+            raise ValueError("Incorrect inference mode")
+        eng = self._engine_for(inputs, _engine.CommEngine)
+        B, N = inputs.shape[0], self.agent_num
+        with torch.no_grad():
+            x = inputs.contiguous() if inputs.dtype == torch.uint8 else inputs.contiguous().float()
+            labels, prob, action, nnz = eng.forward_local(x, B, N, inference, use_graph=self.use_hip_graph,
+                                                          labels=want_labels, confusion=(gt_labels.contiguous(), hist))
+        num_connect = self.agent_num - 1 if inference == "softmax" else int(nnz.sum().item()) / (self.agent_num * B)
+        return labels, prob, action, num_connect
+
     # ---- train-mode path: stock PyTorch ops + autograd (outside the accelerated scope) ------
     def _forward_train_stock_ops(self, inputs, training, MO_flag, inference):
         if not training:

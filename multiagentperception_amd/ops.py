@@ -45,12 +45,16 @@ class KernelTimer:
     Used by bench.py's roofline attribution pass only; never active inside its timed region."""
 
     def __init__(self):
-        self.records = []          # (start_event, end_event, flops, key)
+        self.records = []          # (start_event, end_event, flops, key, algorithmic bytes)
+
+    def algorithmic_bytes(self):
+        """sum over the recorded launches of input + output (+ residual) activations + weights, each once."""
+        return float(sum(r[4] for r in self.records))
 
     def summary(self):
         """-> total_ms, total_flops, launches, per-shape {key: [ms, flops, count]} (call after a sync)."""
         total_ms, total_fl, per = 0.0, 0.0, {}
-        for st, en, fl, key in self.records:
+        for st, en, fl, key, _ in self.records:
             ms = st.elapsed_time(en)
             total_ms += ms
             total_fl += fl
@@ -160,12 +164,35 @@ _MAX_X_BYTES = (1 << 31) - 1       # the conv kernels address x through a 32-bit
 
 
 def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
-               out=None, out_f32=False, out_cstride=None, variant=None, ksplit=None):
+               out=None, out_f32=False, out_cstride=None, variant=None, ksplit=None, out_groups=None, _gstride=0):
     """x: bf16 NHWC [M,H,W,xcs]; the conv reads channels [x_ch_off + g*cin, ...).  Returns/accepts
     out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32).  ksplit: None = one workgroup per tile;
     0 = split-K chosen by the library for tail layers; n = forced n-way split.
     Batches whose activation tensor reaches 2 GiB are run as several launches over slices of M (results are
-    independent of the image count, so the slicing is invisible)."""
+    independent of the image count, so the slicing is invisible).
+    out_groups: one NHWC [M,Ho,Wo,cs] tensor PER GROUP (same shape, dtype and cs >= cout) instead of one side-by-side
+    tensor -- e.g. the value trunk's squeezer writing V straight into its slot of an all-gather buffer; returns them."""
+    if out_groups is not None:
+        if out is not None or residual is not None or len(out_groups) != groups:
+            raise W2CError("conv: out_groups excludes out/residual and needs one tensor per group")
+        g0 = out_groups[0]
+        _need_gpu(*out_groups)
+        esz = g0.element_size()
+        gstride = 0
+        for i, t in enumerate(out_groups):
+            if t.shape != g0.shape or t.dtype != g0.dtype or g0.shape[3] < cout:
+                raise W2CError("conv: out_groups tensors must share shape/dtype with >= cout channels")
+            d = t.data_ptr() - g0.data_ptr()
+            if i == 1:
+                gstride = d // esz
+            if d != i * gstride * esz or d % 16:
+                raise W2CError("conv: out_groups tensors must be evenly spaced, 16-byte aligned")
+        if gstride == 0 and groups > 1:
+            raise W2CError("conv: out_groups tensors alias")
+        conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, relu=relu, out=g0,
+                   out_f32=out_f32, out_cstride=g0.shape[3], variant=variant, ksplit=ksplit, out_groups=None,
+                   _gstride=gstride if groups > 1 else 0)
+        return list(out_groups)
     dev = _need_gpu(x, w_packed, scale, shift, residual, out)
     M, H, W, xcs = x.shape
     pad = 1 if ksize == 3 else 0
@@ -173,6 +200,8 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     Wo = (W + 2 * pad - ksize) // stride + 1
     if out_cstride is None:
         out_cstride = groups * cout
+    if out_cstride < (groups if not _gstride else 1) * cout:
+        raise W2CError("conv: out_cstride %d too small for %d x %d output channels" % (out_cstride, groups, cout))
     if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
         raise W2CError("conv: channels [%d, %d) outside the tensor's %d channels" % (x_ch_off, x_ch_off + groups * cin, xcs))
     if out is None:
@@ -188,7 +217,7 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
             hi = min(M, lo + step)
             conv_igemm(x[lo:hi], x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift,
                        residual=None if residual is None else residual[lo:hi], relu=relu, out=out[lo:hi],
-                       out_f32=out_f32, out_cstride=out_cstride, variant=variant, ksplit=ksplit)
+                       out_f32=out_f32, out_cstride=out_cstride, variant=variant, ksplit=ksplit, _gstride=_gstride)
         return out
     xptr = x.data_ptr() + 2 * x_ch_off
     timer = getattr(_tls, "conv_timer", None)
@@ -208,22 +237,25 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
                                                            groups, _p(scale), _p(shift), _p(residual),
                                                            1 if relu else 0, _p(out), out_cstride,
                                                            1 if out_f32 else 0, _p(zero_page(dev)), int(ksplit),
-                                                           _p(ws), ws.numel(), _stream(dev)), "w2c_conv_igemm_bf16_splitk")
+                                                           _p(ws), ws.numel(), int(_gstride), _stream(dev)),
+                  "w2c_conv_igemm_bf16_splitk")
         elif variant is None:
             check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
                                                     _p(scale), _p(shift), _p(residual), 1 if relu else 0,
                                                     _p(out), out_cstride, 1 if out_f32 else 0,
-                                                    _p(zero_page(dev)), _stream(dev)), "w2c_conv_igemm_bf16")
+                                                    _p(zero_page(dev)), int(_gstride), _stream(dev)), "w2c_conv_igemm_bf16")
         else:
             check(_native.lib().w2c_conv_igemm_bf16_variant(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride,
                                                             groups, _p(scale), _p(shift), _p(residual),
                                                             1 if relu else 0, _p(out), out_cstride,
                                                             1 if out_f32 else 0, _p(zero_page(dev)), int(variant),
-                                                            _stream(dev)), "w2c_conv_igemm_bf16_variant(%d)" % variant)
+                                                            int(_gstride), _stream(dev)), "w2c_conv_igemm_bf16_variant(%d)" % variant)
     if timer is not None:
         ev1.record(torch.cuda.current_stream(dev))
         flops = 2.0 * M * Ho * Wo * cout * (ksize * ksize * cin) * groups
-        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups)))
+        nbytes = (M * H * W * cin * groups * 2 + M * Ho * Wo * cout * groups * (4 if out_f32 else 2)
+                  + (M * Ho * Wo * cout * groups * 2 if residual is not None else 0) + groups * cout * ksize * ksize * cin * 2)
+        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups), nbytes))
     return out
 
 
@@ -260,8 +292,9 @@ def head_tail(h0, col_off, k1, w1t, b1, w2t, b2):
     return out
 
 
-def head_tail2(h0, k1, tail_a, tail_b):
-    """Both heads' tails in one launch: tail_x = (col_off, w1t, b1, w2t, b2) -> (out_a [M,O_a], out_b [M,O_b])."""
+def head_tail2(h0, k1, tail_a, tail_b, out_a=None, out_b=None):
+    """Both heads' tails in one launch: tail_x = (col_off, w1t, b1, w2t, b2) -> (out_a [M,O_a], out_b [M,O_b]);
+    out_a / out_b may be preallocated (e.g. a rank's rows of the key all-gather buffer)."""
     ca, w1a, b1a, w2a, b2a = tail_a
     cb, w1b, b1b, w2b, b2b = tail_b
     dev = _need_gpu(h0, w1a, b1a, w2a, b2a, w1b, b1b, w2b, b2b)
@@ -271,8 +304,13 @@ def head_tail2(h0, k1, tail_a, tail_b):
         raise W2CError("head_tail2: both heads must share the hidden width")
     if min(ca, cb) < 0 or max(ca, cb) + k1 > stride or w1a.shape[0] != k1 or w1b.shape[0] != k1:
         raise W2CError("head_tail2: column ranges / weights do not fit h0 %s" % (tuple(h0.shape),))
-    out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
-    out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
+    if out_a is None:
+        out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
+    if out_b is None:
+        out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
+    for o, w2 in ((out_a, w2a), (out_b, w2b)):
+        if tuple(o.shape) != (M, w2.shape[1]) or o.dtype != torch.float32 or not o.is_contiguous() or o.device != dev:
+            raise W2CError("head_tail2: bad preallocated output %s" % (tuple(o.shape),))
     with torch.cuda.device(dev):
         check(_native.lib().w2c_head_tail2_f32(_p(h0), stride, M, k1, H1, ca, _p(w1a), _p(b1a), _p(w2a), _p(b2a), w2a.shape[1],
                                                _p(out_a), cb, _p(w1b), _p(b1b), _p(w2b), _p(b2b), w2b.shape[1], _p(out_b),
@@ -352,6 +390,41 @@ def upsample32_argmax(low, n_classes):
         check(_native.lib().w2c_upsample32_argmax(_p(low), M, h, w, lcs, n_classes, _p(out), _stream(dev)),
               "w2c_upsample32_argmax")
     return out
+
+
+def _gt_kind(gt):
+    if gt.dtype == torch.uint8:
+        return 0
+    if gt.dtype == torch.int64:
+        return 1
+    raise W2CError("ground-truth labels must be uint8 or int64, got %s" % gt.dtype)
+
+
+def upsample32_argmax_confusion(low, n_classes, gt, hist, want_labels=False):
+    """K9 + class argmax + confusion matrix (metrics.py:99-108) in one launch.  gt: u8 or i64 [M,32h,32w];
+    hist: int64 [n*n] accumulated in place.  Returns the u8 label map when want_labels, else None."""
+    dev = _need_gpu(low, gt, hist)
+    M, h, w, lcs = low.shape
+    if tuple(gt.shape) != (M, 32 * h, 32 * w):
+        raise W2CError("confusion: labels %s do not match the %s prediction map" % (tuple(gt.shape), (M, 32 * h, 32 * w)))
+    if hist.dtype != torch.int64 or hist.numel() != n_classes * n_classes:
+        raise W2CError("confusion: hist must be int64 [%d]" % (n_classes * n_classes))
+    out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev) if want_labels else None
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_upsample32_argmax_confusion(_p(low), M, h, w, lcs, n_classes, _p(gt), _gt_kind(gt), _p(out),
+                                                            _p(hist), _stream(dev)), "w2c_upsample32_argmax_confusion")
+    return out
+
+
+def confusion_matrix(gt, pred, n_classes, hist):
+    """hist[n*gt + pred] += 1 on the device (gt u8/i64, pred u8, same shape); hist int64 [n*n]."""
+    dev = _need_gpu(gt, pred, hist)
+    if gt.shape != pred.shape or pred.dtype != torch.uint8 or hist.dtype != torch.int64 or hist.numel() != n_classes ** 2:
+        raise W2CError("confusion_matrix: bad arguments")
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_confusion_matrix(_p(gt), _gt_kind(gt), _p(pred), gt.numel(), n_classes, _p(hist),
+                                                 _stream(dev)), "w2c_confusion_matrix")
+    return hist
 
 
 def nchw_f32_to_nhwc_bf16(x, cstride=None):

@@ -101,12 +101,76 @@ def shard_agents(agent_num, world, rank):
     return rank * n_loc, n_loc
 
 
+def _gather_inplace(buf, rank, rows, group=None):
+    """all-gather where every rank's shard already sits in its own rows [rank*rows, (rank+1)*rows) of `buf` (the
+    producing kernels wrote it there: no staging copy).  RCCL does this in place; other backends (gloo in the tests)
+    get a private copy of the shard as the send buffer.  Returns the async work handle."""
+    mine = buf[rank * rows:(rank + 1) * rows]
+    if dist.get_backend(group) != "nccl":
+        mine = mine.clone()
+    return dist.all_gather_into_tensor(_as_bytes_view(buf), _as_bytes_view(mine), group=group, async_op=True)
+
+
+class _ShardState:
+    """Static buffers + captured segments of one (engine, input shape) pair on one rank."""
+
+    def __init__(self, eng, x, n_loc, N, q_lo):
+        B, _, H, W = x.shape
+        dev = x.device
+        h, w = H // 32, W // 32
+        bf16 = torch.bfloat16
+        self.B, self.N, self.n_loc, self.q_lo = B, N, n_loc, q_lo
+        self.s0 = torch.empty((n_loc * B, H // 4, W // 4, 64 * eng.trunk.G), dtype=bf16, device=dev)   # pooled stem output
+        self.v_all = torch.zeros((N * B, h, w, eng.feat), dtype=bf16, device=dev)       # every agent's value map
+        self.pol = torch.empty((n_loc * B, h, w, eng.feat), dtype=bf16, device=dev)     # local policy-encoder map
+        dq = eng.wq.shape[1]
+        self.k_all = torch.zeros((N * B, dq + 1), dtype=torch.float32, device=dev)      # projected keys of every agent
+        self.q_loc = torch.empty((n_loc * B, dq), dtype=torch.float32, device=dev) if eng.has_query else None
+        lo, hi = q_lo * B, (q_lo + n_loc) * B
+        self.v_slot = self.v_all[lo:hi]
+        self.k_slot = self.k_all[lo:hi]
+        self.graphs = {}
+        self.out = {}
+
+    def run(self, name, fn, use_graph):
+        """Run segment `name` (fn() -> tuple of tensors written into static buffers), eagerly or by replaying its
+        captured HIP graph (captured on first use, after two warm-up runs on a side stream)."""
+        if not use_graph:
+            self.out[name] = fn()
+            return self.out[name]
+        g = self.graphs.get(name)
+        if g is None:
+            dev = self.v_all.device
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fn()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                res = fn()
+            self.graphs[name] = (g, res)
+            g = self.graphs[name]
+        g[0].replay()
+        self.out[name] = g[1]
+        return g[1]
+
+
 class AgentParallelForward:
     """Callable mirroring MIMOcom.forward for a rank's local agents.
 
     inputs_local: f32 [B, 3*n_loc, H, W] (this rank's agents' frames).
     Returns (pred [n_loc*B, n_cls, H, W], prob [B, N, n_loc], action [B, n_loc], nnz [B])
-    for the local query agents; N = global agent count."""
+    for the local query agents; N = global agent count.
+
+    Per step and rank ('softmax'): stem (eager: reads the caller's tensor) -> segment A: layer1..4 + both squeezers, the
+    value trunk's squeezer writing V straight into this rank's rows of the all-gather buffer -> async all-gather of V
+    (in place, RCCL) -> segment B: policy tail + heads, the projected keys written into this rank's rows of the key
+    buffer (runs while V is on the wire) -> all-gather of K -> segment C: graph columns of the local queries, fusion,
+    decoder convs -> upsample (eager: caller-owned output).  With model.use_hip_graph the three segments are replayed
+    from captured HIP graphs (~45 launches -> 3); the collectives stay eager between them."""
 
     def __init__(self, model, group=None):
         from . import engine as _engine
@@ -116,8 +180,19 @@ class AgentParallelForward:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.q_lo, self.n_loc = shard_agents(model.agent_num, self.world, self.rank)
         self._engine_cls = _engine.CommEngine
+        self.last_exchange = None
+
+    def _state(self, eng, x):
+        cache = eng.__dict__.setdefault("_shard_states", {})          # dies with the engine (load_state_dict / .to() / train())
+        key = (tuple(x.shape), self.world, self.rank)
+        st = cache.get(key)
+        if st is None:
+            st = _ShardState(eng, x, self.n_loc, self.model.agent_num, self.q_lo)
+            cache[key] = st
+        return st
 
     def __call__(self, inputs_local, inference="softmax"):
+        from . import ops
         model = self.model
         if model.training:
             raise RuntimeError("agent-parallel forward is the eval (HIP) path; call model.eval()")
@@ -125,40 +200,49 @@ class AgentParallelForward:
                                                                   # .to() / train() drop the model's packed weights)
         B = inputs_local.shape[0]
         N = model.agent_num
+        use_graph = bool(getattr(model, "use_hip_graph", False))
         with torch.no_grad():
             x = inputs_local.contiguous().float()
             if self.world == 1:
-                return eng.forward_local(x, B, N, inference, use_graph=getattr(model, "use_hip_graph", False))
-            sq = eng.trunk.run(x, self.n_loc)                                  # [n_loc*B,h,w,1024]
+                return eng.forward_local(x, B, N, inference, use_graph=use_graph)
+            st = self.encode_local(eng, x, use_graph)
             if inference != "softmax":
-                return self._sparse(eng, sq, B, N, inference)
-            v_loc = sq[..., :eng.feat].contiguous() if self.world > 1 else None
-            v_all, v_work = exchange_start(v_loc, self.group) if self.world > 1 else (None, None)
-            keys, querys = eng.policy_tail(sq)                                 # overlaps the V all-gather
-            if self.world > 1:
-                k_all, k_work = exchange_start(keys, self.group)
-                exchange_wait(v_work)
-                exchange_wait(k_work)
-                v_src, v_ch = v_all, eng.feat
-            else:
-                k_all, v_src = keys, sq
-            pred, prob, action, nnz, _ = eng.graph_and_decode(v_src, k_all, querys, B, N, self.q_lo, self.n_loc,
-                                                              inference)
+                return self._sparse(eng, st, inference, use_graph)
+            v_work = _gather_inplace(st.v_all, self.rank, self.n_loc * B, self.group)
+            st.run("B", lambda: eng.policy_tail(st.pol, ch_off=0, outs=(st.k_slot, st.q_loc)), use_graph)   # under the V gather
+            k_work = _gather_inplace(st.k_all, self.rank, self.n_loc * B, self.group)
+            exchange_wait(v_work)
+            exchange_wait(k_work)
+            low, prob, action, nnz = st.run(
+                "C:softmax", lambda: eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, "softmax"),
+                use_graph)
+            pred = ops.upsample_bilinear32(low, eng.n_classes)
+        if use_graph:
+            prob, action, nnz = prob.clone(), action.clone(), nnz.clone()
         return pred, prob, action, nnz
 
-    def _sparse(self, eng, sq, B, N, inference):
+    def encode_local(self, eng, x, use_graph=False):
+        """stem + segment A on this rank's frames: V of the local agents lands in st.v_slot (= their rows of st.v_all),
+        the policy-encoder map in st.pol.  Returns the shard state."""
+        st = self._state(eng, x)
+        eng.trunk.stem(x, self.n_loc, out=st.s0)
+        st.run("A", lambda: tuple(eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol])), use_graph)
+        return st
+
+    def _sparse(self, eng, st, inference, use_graph=False):
         """'activated' / 'argmax_test' across ranks, handshake-ordered: tiny exchange of projected keys
         and queries -> every rank evaluates the whole graph -> only the value maps with a non-zero fusion weight cross
         xGMI.  self.last_exchange = (maps received, maps an all-gather would have received)."""
         from . import ops
-        keys, querys = eng.policy_tail(sq)
-        k_all, k_work = exchange_start(keys, self.group)
-        q_all, q_work = (exchange_start(querys, self.group) if querys is not None else (None, None))
+        B, N = st.B, st.N
+        st.run("B", lambda: eng.policy_tail(st.pol, ch_off=0, outs=(st.k_slot, st.q_loc)), use_graph)
+        k_work = _gather_inplace(st.k_all, self.rank, self.n_loc * B, self.group) if self.world > 1 else None
+        q_all, q_work = (exchange_start(st.q_loc, self.group) if st.q_loc is not None else (None, None))
         exchange_wait(k_work)
         exchange_wait(q_work)
-        _, coef_full, _, _ = ops.comm_graph_projected(q_all, k_all, B, N, eng.who, inference)     # [B, N, N], same on every rank
+        _, coef_full, _, _ = ops.comm_graph_projected(q_all, st.k_all, B, N, eng.who, inference)   # [B, N, N], same on every rank
         need = (coef_full != 0).cpu()                                          # the handshake's one host round trip
-        v_all, got, dense = sparse_exchange(sq[..., :eng.feat].contiguous(), need, B, N, self.group)
+        v_all, got, dense = sparse_exchange(st.v_slot, need, B, N, self.group)
         self.last_exchange = (got, dense)
-        pred, prob, action, nnz, _ = eng.graph_and_decode(v_all, k_all, querys, B, N, self.q_lo, self.n_loc, inference)
+        pred, prob, action, nnz, _ = eng.graph_and_decode(v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, inference)
         return pred, prob, action, nnz

@@ -566,3 +566,52 @@ def test_bad_arguments_raise_not_abort():
     s = torch.ones(64, device=_dev())
     with pytest.raises(W2CError):
         ops.conv_igemm(x, 0, 48, w, 64, 3, 1, 1, s, s)                        # Cin % 64 != 0
+
+
+@pytest.mark.parametrize("gt_dtype", [torch.uint8, torch.int64])
+def test_confusion_matrix_matches_reference_running_score(gt_dtype):
+    """w2c_confusion_matrix vs the reference's runningScore on the committed fixture (tests/golden/metrics_unit.npz, made
+    by oracle/make_golden.py from /root/reference/ptsemseg/metrics.py:99-108), plus uniform maps (the wave-uniform fast
+    path) and out-of-range labels (the reference's mask)."""
+    import os
+    from multiagentperception_amd import ops
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_unit.npz"))
+    from oracle import filler
+    gt = filler.synthetic_labels(4, 64, 64, 5)              # the inputs oracle/make_golden.py fed to runningScore.update
+    pr = filler.synthetic_labels(4, 64, 64, 6)
+    gt[filler.synthetic_labels(4, 64, 64, 7) == 0] = 250    # the ignore label
+    pr[:, :, :8] = 3
+    pr[pr == 9] = 2
+    hist = torch.zeros(121, dtype=torch.int64, device=_dev())
+    ops.confusion_matrix(torch.from_numpy(gt).to(gt_dtype).to(_dev()), torch.from_numpy(pr).to(torch.uint8).to(_dev()), 11, hist)
+    np.testing.assert_array_equal(hist.cpu().numpy().reshape(11, 11), g["hist"].astype(np.int64))
+    # accumulation + masked labels + constant regions
+    gen = torch.Generator().manual_seed(5)
+    gt2 = torch.randint(0, 14, (3, 64, 96), generator=gen)              # 11..13 are out of range
+    gt2[1] = 4
+    pr2 = torch.randint(0, 11, (3, 64, 96), generator=gen).to(torch.uint8)
+    pr2[1, :, :48] = 9
+    ops.confusion_matrix(gt2.to(gt_dtype).to(_dev()), pr2.to(_dev()), 11, hist)
+    keep = gt2 < 11
+    want = g["hist"].astype(np.int64) + np.bincount((11 * gt2[keep] + pr2[keep].long()).numpy(), minlength=121).reshape(11, 11)
+    np.testing.assert_array_equal(hist.cpu().numpy().reshape(11, 11), want)
+
+
+def test_upsample32_argmax_confusion_equals_separate_steps():
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    M, h, w = 3, 4, 6
+    low = torch.randn(M, h, w, 32, generator=gen).to(_dev())
+    low[1] = 0.0
+    low[1, ..., 3] = 1.0                                                # a whole image in one class: wave-uniform bins
+    gt = torch.randint(0, 12, (M, 32 * h, 32 * w), generator=gen)       # 11 = ignored
+    gt[1, :40] = 2
+    lab = ops.upsample32_argmax(low, 11)
+    for dt in (torch.uint8, torch.int64):
+        hist = torch.zeros(121, dtype=torch.int64, device=_dev())
+        got = ops.upsample32_argmax_confusion(low, 11, gt.to(dt).to(_dev()), hist, want_labels=True)
+        assert torch.equal(got, lab)
+        assert ops.upsample32_argmax_confusion(low, 11, gt.to(dt).to(_dev()), hist) is None       # accumulates a second time
+        keep = gt < 11
+        want = np.bincount((11 * gt[keep] + lab.cpu()[keep].long()).numpy(), minlength=121)
+        np.testing.assert_array_equal(hist.cpu().numpy(), 2 * want)

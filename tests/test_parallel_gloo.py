@@ -150,3 +150,36 @@ def test_sparse_plan_is_consistent_between_the_two_ends():
             send_local = plans[r][0][s]                              # rows of r's shard that go to s
             recv_global = plans[s][1][r]                             # rows s expects from r
             assert [r * n_loc * B + i for i in send_local] == recv_global
+
+
+def _inplace_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiagentperception_amd import parallel
+    rows = 3
+    buf = torch.full((world * rows, 4, 5), -1.0).to(torch.bfloat16)
+    buf[rank * rows:(rank + 1) * rows] = torch.arange(rows * 20, dtype=torch.float32).reshape(rows, 4, 5).to(torch.bfloat16) + 100 * rank
+    kbuf = torch.zeros(world * rows, 33)
+    kbuf[rank * rows:(rank + 1) * rows] = torch.arange(rows * 33, dtype=torch.float32).reshape(rows, 33) * (rank + 1)
+    w1 = parallel._gather_inplace(buf, rank, rows)
+    w2 = parallel._gather_inplace(kbuf, rank, rows)
+    parallel.exchange_wait(w1)
+    parallel.exchange_wait(w2)
+    torch.save(dict(buf=buf.float(), kbuf=kbuf), os.path.join(out_dir, "ip%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inplace_gather_of_preplaced_shards(tmp_path):
+    """The agent-parallel path has its kernels write V / K straight into the rank's rows of the gather buffer
+    (parallel._gather_inplace): after the collective every rank holds every shard at its owner's rows."""
+    world, rows = 2, 3
+    mp.spawn(_inplace_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = torch.cat([torch.arange(rows * 20, dtype=torch.float32).reshape(rows, 4, 5).to(torch.bfloat16).float() + 100 * r
+                      for r in range(world)], 0)
+    wantk = torch.cat([torch.arange(rows * 33, dtype=torch.float32).reshape(rows, 33) * (r + 1) for r in range(world)], 0)
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), "ip%d.pt" % r))
+        np.testing.assert_array_equal(d["buf"].numpy(), want.numpy())
+        np.testing.assert_array_equal(d["kbuf"].numpy(), wantk.numpy())

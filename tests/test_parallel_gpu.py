@@ -27,7 +27,7 @@ def _cfg(n, size):
     return {"model": model, "data": {"img_rows": size, "img_cols": size}}
 
 
-def _worker(rank, world, port, N, B, S, seed, mode, out_dir):
+def _worker(rank, world, port, N, B, S, seed, mode, out_dir, graph=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,6 +40,10 @@ def _worker(rank, world, port, N, B, S, seed, mode, out_dir):
     q_lo, n_loc = shard_agents(N, world, rank)
     x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
     fwd = AgentParallelForward(model)
+    model.use_hip_graph = graph
+    if graph:        # capture on OTHER frames first, so the checked call is a pure replay through the static buffers
+        other = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed + 1))
+        fwd(other[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
     pred, prob, action, nnz = fwd(x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
     torch.cuda.synchronize()
     torch.save(dict(pred=pred.cpu(), prob=prob.cpu(), action=action.cpu(), q_lo=q_lo, n_loc=n_loc,
@@ -48,12 +52,13 @@ def _worker(rank, world, port, N, B, S, seed, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["softmax", "activated", "argmax_test"])
-def test_two_rank_agent_parallel_forward_equals_unsharded(tmp_path, mode):
+@pytest.mark.parametrize("mode,graph", [("softmax", False), ("softmax", True), ("activated", False), ("activated", True),
+                                        ("argmax_test", False)])
+def test_two_rank_agent_parallel_forward_equals_unsharded(tmp_path, mode, graph):
     from oracle import filler
     from ptsemseg.models import get_model
     world, N, B, S, seed = 2, 4, 2, 128, 321
-    mp.spawn(_worker, args=(world, _free_port(), N, B, S, seed, mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, B, S, seed, mode, str(tmp_path), graph), nprocs=world, join=True)
     model = get_model(_cfg(N, S), 11)
     filler.apply_to_module(model)
     model = model.to("cuda:0").eval()
@@ -72,3 +77,24 @@ def test_two_rank_agent_parallel_forward_equals_unsharded(tmp_path, mode):
         if mode != "softmax":
             got, dense = d["exch"]
             assert dense == (world - 1) * n * B and 0 <= got <= dense
+
+
+def test_bench_self_launches_its_ranks_and_reports_comm(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the script must start its own ranks,
+    run the sharded 3-segment graph path and print ONE JSON line with n_gpus, the rank count and the collectives' time.
+    Two ranks share this box's single GPU, so the transport is gloo (RCCL refuses that); shapes = cfg3 scaled down."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "cfg3",
+                        "--batch", "1", "--size", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["agents_total"] == 8
+    assert d["config"]["agents_per_gpu"] == 4 and d["comm"]["ranks"] == 2 and d["comm"]["us_per_step_unoverlapped"] > 0
+    assert d["value"] > 0 and d["roofline"]["launches_per_step"] == 27
