@@ -131,6 +131,12 @@ def _is_conv_kernel(name):
     return ("conv_igemm_kernel" in name or "conv3x3_" in name or "splitk_finish_kernel" in name or "conv_mx" in name)
 
 
+def _short_kernel(name):
+    import re
+    m = re.search(r"((?:conv_igemm_kernel|conv3x3_patch_kernel|conv3x3_c64_regw_kernel|splitk_finish_kernel)(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:64]
+
+
 def pmc_child(args, preset):
     """Child of the PMC passes: `--pmc-child R` runs exactly R identical eager forwards and nothing else."""
     dev = torch.device("cuda", 0)
@@ -174,7 +180,7 @@ def pmc_traffic(args, reps=4, timeout=240):
                     if row["Counter_Name"] == counter and _is_conv_kernel(row["Kernel_Name"]):
                         v = float(row["Counter_Value"]) * 1024.0
                         tot += v
-                        key = row["Kernel_Name"].split("(")[0][:64] + " grid=" + row["Grid_Size"]
+                        key = _short_kernel(row["Kernel_Name"]) + " grid=" + row["Grid_Size"]
                         e = per_kernel.setdefault(key, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
                         e[counter] += v
                         if counter == "FETCH_SIZE":

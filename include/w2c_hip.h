@@ -129,6 +129,28 @@ int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W, int Cin, 
 long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,
                                           int groups, int ksplit);
 
+/* ---- cfg 5 (BASELINE.json configs[4]: "fp8 encoder convs on CDNA4 MFMA"): the same convolution with fp8 operands.
+ * x_is_fp8 = 1: x and w are OCP e4m3fn bytes (x NHWC with x_cstride BYTES-per-pixel channels, w
+ * [groups][Cout][ksize*ksize][Cin]); the kernels issue v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales --
+ * gfx950's only 2x-rate fp8 MFMA -- over K-steps of 128 channels (the same 128-byte rows as the bf16 form, so the same
+ * tiles, swizzles and LDS-DMA schedule, with half the K-steps).  Quantisation scales are the caller's: per-output-
+ * channel weight scales and the per-tensor input scale are folded into `scale` (y = act(acc*scale + shift + residual)).
+ * x_is_fp8 = 0: bf16 operands (as w2c_conv_igemm_bf16); used where a bf16 tensor must produce an fp8 one.
+ * Outputs (either or both): y_bf16 (pixel stride y_cstride, groups y_group_stride apart, 0 = Cout) and y_fp8 =
+ * e4m3(result / y8_scale), saturated at +-448, groups side by side, pixel stride y8_cstride.  Cin multiple of 128 (fp8) /
+ * 64 (bf16).  variant < 0: library's choice.  Results are independent of M and of the variant (one K order). */
+int w2c_conv_igemm_fp8(const void* x, int x_is_fp8, int M, int H, int W, int Cin, int x_cstride,
+                       const void* w, int Cout, int ksize, int stride, int groups,
+                       const float* scale, const float* shift,
+                       const uint16_t* residual, int relu,
+                       uint16_t* y_bf16, int y_cstride, long long y_group_stride,
+                       uint8_t* y_fp8, int y8_cstride, float y8_scale,
+                       const void* zero_page, int variant, w2c_stream_t stream);
+/* Unit-test probes of the two fp8 primitives: c[32][32] f32 = a[32][64] . b[32][64]^T (e4m3, one MX-scaled MFMA with
+ * unit block scales); y[n] = e4m3(x[n]) as the conv epilogues pack it (round to nearest even, saturating). */
+int w2c_debug_mx_mfma(const uint8_t* a, const uint8_t* b, float* c, w2c_stream_t stream);
+int w2c_debug_fp8_pack(const float* x, uint8_t* y, int n, w2c_stream_t stream);
+
 /* Debug aid (tools/conv_timeline.py): the calling thread's NEXT w2c_conv_igemm_bf16_variant launch records
  * 4 x uint64 wall-clock stamps per workgroup (start, first tile landed, main loop done, end; 100 MHz) into buf
  * (device memory, >= 32 bytes x workgroups). */

@@ -32,6 +32,10 @@ SIGNATURES = {
                                    _vp, _ll, _ll, _vp],
     "w2c_conv_splitk_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_debug_conv_timeline": [_vp],
+    "w2c_conv_igemm_fp8": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _vp, _i, _f,
+                           _vp, _i, _vp],
+    "w2c_debug_mx_mfma": [_vp, _vp, _vp, _vp],
+    "w2c_debug_fp8_pack": [_vp, _vp, _i, _vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "w2c_head_tail_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp],
     "w2c_head_tail2_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

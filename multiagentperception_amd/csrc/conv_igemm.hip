@@ -53,7 +53,36 @@ struct ConvArgs {
     float* ws;                 // split-K: f32 partial tiles [group][tile][split][BM][BN]
     int n_split;
     long long ygs;             // element offset between the groups' output (and residual) slabs; Cout = side by side
+    uint8_t* y8;               // optional second output: fp8 e4m3 copy of the result (groups side by side), value * q8
+    int y8cs;
+    float q8;
 };
+
+// element size / channels per K-step of the two operand types: a K-step is always ONE 128-byte run per row
+template <bool F8> struct OpT { static constexpr int ES = F8 ? 1 : 2; static constexpr int CK = F8 ? 128 : 64; };
+
+// 8 consecutive output channels of one pixel -> the outputs selected by (p.y, p.y_f32, p.y8)
+__device__ __forceinline__ void store_out8(const ConvArgs& p, const float (&v)[8], size_t off, size_t off8) {
+    if (p.y) {
+        if (p.y_f32) {
+            float* yo = reinterpret_cast<float*>(p.y) + off;
+            *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+        } else {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + off) = o;
+        }
+    }
+    if (p.y8) {
+        uint2 o;
+        o.x = pack_fp8x4(v[0] * p.q8, v[1] * p.q8, v[2] * p.q8, v[3] * p.q8);
+        o.y = pack_fp8x4(v[4] * p.q8, v[5] * p.q8, v[6] * p.q8, v[7] * p.q8);
+        *reinterpret_cast<uint2*>(p.y8 + off8) = o;
+    }
+}
+
 
 __device__ __forceinline__ void dbg_stamp(const ConvArgs& p, int slot) {
     if (p.dbg && threadIdx.x == 0)
@@ -79,13 +108,14 @@ __device__ __forceinline__ void pipeline_barrier() {
 // tiles go to p.ws as f32 and splitk_finish_kernel sums them in split order (fixed order: deterministic) and runs
 // the epilogue.  For the tail layers (<= 80 tiles under a long, weight-streaming K loop) this turns a 36-step
 // latency chain into 4-5 steps on 8x the CUs.
-template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool SPLITK = false>
+template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool SPLITK = false, bool F8 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;        // wave tile
     constexpr int MI = WTM / 32, NI = WTN / 32;        // 32x32 MFMA tiles per wave
-    constexpr int ROWB = BK * 2;                       // bytes per LDS row
+    constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;  // operand bytes per element / channels per K-step
+    constexpr int ROWB = BK * 2;                       // bytes per LDS row (128: 64 bf16 or 128 fp8 channels)
     constexpr int LPR = ROWB / 16;                     // lanes (16-B chunks) per row: 8 or 4
     constexpr int RPI = 64 / LPR;                      // rows per DMA wave-instruction: 8 or 16
     constexpr int A_INSTR = BM / RPI / NW;             // DMA instructions per wave per K-step
@@ -112,18 +142,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const uint16_t* xg = p.x + (size_t)g * p.Cin;                      // group's channel slice
-    const int Ktot = p.ktiles * BK;
-    const uint16_t* wg = p.w + (size_t)g * p.Cout * Ktot;              // group's weights
+    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)g * p.Cin * ES;      // group's channel slice
+    const int Ktot = p.ktiles * CK;                                                    // elements per weight row
+    const char* wg = reinterpret_cast<const char*>(p.w) + (size_t)g * p.Cout * Ktot * ES;   // group's weights
 
     // ---- DMA addressing: buffer loads to LDS (SGPR descriptor + per-lane 32-bit byte offset + scalar
     // channel-chunk offset).  A row's offset for tap (ky,kx) is base + tap_off with tap_off wave-uniform;
     // taps that fall outside the image (and rows past the end) get an offset past the descriptor's extent, so
     // the hardware bounds check writes zeros into LDS -- no zero page, no 64-bit per-lane address math. ----
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+        const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(wg), 0, (int)((size_t)p.Cout * Ktot * 2), 0x00020000);
+        const_cast<char*>(wg), 0, (int)((size_t)p.Cout * Ktot * ES), 0x00020000);
     const int lrow = lane / LPR;           // row within a DMA group
     const int lpos = lane % LPR;           // 16-B position within the LDS row
     auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_iy0[j] = oy * p.stride - p.pad;
             a_ix0[j] = ox * p.stride - p.pad;
-            a_base[j] = (int)((((long)m * p.H * p.W + (long)a_iy0[j] * p.W + a_ix0[j]) * p.xcs + chunk * 8) * 2);
+            a_base[j] = (int)(((long)m * p.H * p.W + (long)a_iy0[j] * p.W + a_ix0[j]) * p.xcs * ES + chunk * 16);
         } else {
             a_iy0[j] = -100000; a_ix0[j] = 0; a_base[j] = 0;      // every tap out of range -> zeros
         }
@@ -150,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
         const int n = (wave + NW * j) * RPI + lrow;
-        b_off[j] = (unsigned)(((size_t)(n0 + n) * Ktot + (lpos ^ swz(n)) * 8) * 2);
+        b_off[j] = (unsigned)((size_t)(n0 + n) * Ktot * ES + (lpos ^ swz(n)) * 16);
     }
 
     // K-step range of this workgroup and cursor (wave-uniform): tap (ky,kx) and channel chunk
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     auto stage = [&](int buf) {
         char* As = smem + buf * STAGE_BYTES;
         char* Bs = As + A_BYTES;
-        const int tap_off = (st_ky * p.W + st_kx) * p.xcs * 2;       // wave-uniform, bytes
+        const int tap_off = (st_ky * p.W + st_kx) * p.xcs * ES;      // wave-uniform, bytes
         const int c_off = st_ct * BK * 2;                            // channel chunk, bytes (scalar offset)
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
@@ -180,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(Bs + (wave + NW * j) * 1024), 16, b_off[j],
-                                                     ((st_ky * p.ks + st_kx) * p.Cin + st_ct * BK) * 2, 0, 0);
+                                                     (st_ky * p.ks + st_kx) * p.Cin * ES + st_ct * BK * 2, 0, 0);
         if (++st_kx == p.ks) {
             st_kx = 0;
             if (++st_ky == p.ks) { st_ky = 0; ++st_ct; }
@@ -208,6 +238,40 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE_BYTES;
         const char* Bs = As + A_BYTES;
+        if constexpr (F8) {
+            // fp8 e4m3 operands: the 128-byte row is 128 channels = two K=64 MX-scaled MFMAs (all block scales 2^0:
+            // per-channel / per-tensor scales live in the epilogue's scale[]).  Lane-half lhi of MFMA j takes the 32
+            // bytes at chunks {4j + 2 lhi, 4j + 2 lhi + 1} of its row -- the SAME bytes-to-K assignment for the pixel
+            // and the weight operand, which is all a dot product needs.
+            i32x8_t a8[2][MI], b8[2][NI];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int p0 = ((j2 * 4 + lhi * 2) ^ lswz) << 4, p1 = ((j2 * 4 + lhi * 2 + 1) ^ lswz) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const char* r = As + (wm * WTM + i * 32 + l31) * ROWB;
+                    a8[j2][i] = cat_i32x8(*reinterpret_cast<const u32x4_t*>(r + p0), *reinterpret_cast<const u32x4_t*>(r + p1));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const char* r = Bs + (wn * WTN + j * 32 + l31) * ROWB;
+                    b8[j2][j] = cat_i32x8(*reinterpret_cast<const u32x4_t*>(r + p0), *reinterpret_cast<const u32x4_t*>(r + p1));
+                }
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j2][j], a8[j2][i], acc[i][j], 0, 0, 0,
+                                                                                    0x7F7F7F7F, 0, 0x7F7F7F7F);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)             // keep the MFMAs of this K-step in this K-step (see the patch kernel)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc[i][j]));
+            return;
+        }
         bf16x8_t a[KSUB][MI], b[KSUB][NI];
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) {
@@ -256,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     constexpr int CG = BN / 8;                     // 8-channel groups per row
     constexpr int PASSES = BM * CG / NT;
     static_assert(PASSES * NT == BM * CG, "epilogue split");
-    size_t e_off[PASSES];
+    size_t e_off[PASSES], e_off8[PASSES];
     bool e_ok[PASSES];
     uint4 e_res[PASSES];
 #pragma unroll
@@ -266,6 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         const int gr = m0 + r;
         e_ok[ps] = gr < p.rows;
         e_off[ps] = (size_t)(e_ok[ps] ? gr : 0) * p.ycs + (size_t)g * p.ygs + n0 + cg * 8;
+        e_off8[ps] = (size_t)(e_ok[ps] ? gr : 0) * p.y8cs + (size_t)g * p.Cout + n0 + cg * 8;
     }
     if (p.res && !SPLITK) {
 #pragma unroll
@@ -322,18 +387,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (e_ok[ps]) {
-            if (p.y_f32) {
-                float* yo = reinterpret_cast<float*>(p.y) + e_off[ps];
-                *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
-            } else {
-                uint4 o;
-                o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-                o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + e_off[ps]) = o;
-            }
-        }
+        if (e_ok[ps]) store_out8(p, v, e_off[ps], e_off8[ps]);
     }
     dbg_stamp(p, 3);
 #endif
@@ -352,9 +406,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 // one barrier per tap, counted vmcnt, patch double-buffered across channel chunks.
 // LDS patch image: one 128-B row per patch pixel, 16-B chunk c of pixel q at c ^ ((q>>1)&7) -- the
 // ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
-template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB, bool F8 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
+    constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;  // operand bytes per element / channels per 128-byte K-step
     constexpr int BM = TH * TW;
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -389,10 +444,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     const int img = tsp / (tiles_x * tiles_y);
     const int y0 = tyi * TH, x0 = txi * TW, n0 = tn * BN;
 
-    const uint16_t* xg = p.x + (size_t)g * p.Cin;
+    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)g * p.Cin * ES;
     const int Ktot = 9 * p.Cin;
-    const uint16_t* wg = p.w + (size_t)g * p.Cout * Ktot;
-    const int nchunks = p.Cin >> 6;
+    const char* wg = reinterpret_cast<const char*>(p.w) + (size_t)g * p.Cout * Ktot * ES;
+    const int nchunks = p.Cin / CK;
     const int KT = nchunks * 9;
 
     // ---- DMA addressing: buffer loads to LDS.  Each lane's byte offset inside the tensor is fixed for the
@@ -401,9 +456,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     // flat 64-bit-address LDS-DMA, tools/conv_phases.py).  Halo pixels outside the image carry an offset
     // past the descriptor's extent, so the hardware bounds check writes zeros -- no zero page, no select.
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+        const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(wg), 0, (int)((size_t)p.Cout * Ktot * 2), 0x00020000);
+        const_cast<char*>(wg), 0, (int)((size_t)p.Cout * Ktot * ES), 0x00020000);
     // Rounds whose first pixel is past the patch are skipped by the whole wave (wave-uniform test), so the
     // number of VMEM ops a wave has in flight is EXACTLY known: the last round exists only for some waves.
     const bool p_last = (wave + NW * (P_INSTR - 1)) * 8 < NP;       // does this wave issue round P_INSTR-1 ?
@@ -415,7 +470,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         const int chunk = lpos ^ ((px >> 1) & 7);                    // swizzle keyed on the patch COLUMN (see load_frags)
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        pa_off[j] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.xcs + chunk * 8) * 2) : 0x80000000u;
+        pa_off[j] = ok ? (unsigned)((((long)img * p.H + iy) * p.W + ix) * p.xcs * ES + chunk * 16) : 0x80000000u;
     }
     auto issue_patch = [&](int cc, int buf) {
         char* dst = patch0 + buf * PATCH_BYTES;
@@ -439,12 +494,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
         const int n = (wave + NW * j) * 8 + lrow;
-        b_off[j] = (unsigned)(((size_t)(n0 + n) * Ktot + (lpos ^ ((n >> 1) & 7)) * 8) * 2);
+        b_off[j] = (unsigned)((size_t)(n0 + n) * Ktot * ES + (lpos ^ ((n >> 1) & 7)) * 16);
     }
     int st_tap = 0, st_cc = 0;                                  // cursor of the next weight tile to issue
     auto issue_b = [&](int buf) {
         char* dst = bring + buf * B_BYTES;
-        const int koff = (st_tap * p.Cin + st_cc * 64) * 2;     // scalar byte offset of the K-step
+        const int koff = st_tap * p.Cin * ES + st_cc * 128;     // scalar byte offset of the K-step
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(dst + (wave + NW * j) * 1024), 16, b_off[j], koff, 0, 0);
@@ -476,7 +531,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssp), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssp + 4);
     const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
 
-    bf16x8_t fa[4][MI], fb[4][NI];                              // fragment registers of ONE K-step (tap)
+    bf16x8_t fa[F8 ? 1 : 4][MI], fb[F8 ? 1 : 4][NI];            // fragment registers of ONE K-step (tap)
+    i32x8_t fa8[F8 ? 2 : 1][MI], fb8[F8 ? 2 : 1][NI];           // fp8 form: two K=64 MFMAs per 128-byte row
     // LDS slot of chunk c of patch pixel (row, col): c ^ ((col >> 1) & 7), at byte (row*PW + col)*128.  Keyed on the COLUMN:
     // a wave's 32 pixels lie on two patch rows when TW = 16, and ds_read_b128 services lanes {0-3,12-15,20-27} (etc.)
     // together -- columns {c..c+3, c+12..c+15} of one row and {c+4..c+11} of the next, a complete residue system mod 16 =>
@@ -491,8 +547,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
             arow[i] = patch + pp * 128;
             aswz[i] = ((pc0[i] + kx) >> 1) & 7;
         }
+        if constexpr (F8) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int c0 = j2 * 4 + lhi * 2;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    fa8[j2][i] = cat_i32x8(*reinterpret_cast<const u32x4_t*>(arow[i] + ((c0 ^ aswz[i]) << 4)),
+                                           *reinterpret_cast<const u32x4_t*>(arow[i] + (((c0 + 1) ^ aswz[i]) << 4)));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const char* r = Bs + (wn * WTN + j * 32 + l31) * 128;
+                    fb8[j2][j] = cat_i32x8(*reinterpret_cast<const u32x4_t*>(r + ((c0 ^ bswz) << 4)),
+                                           *reinterpret_cast<const u32x4_t*>(r + (((c0 + 1) ^ bswz) << 4)));
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < (F8 ? 1 : 4); ++kk) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 fa[kk][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + (((kk * 2 + lhi) ^ aswz[i]) << 4));
@@ -503,8 +576,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         }
     };
     auto mfma_all = [&]() {
+        if constexpr (F8) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb8[j2][j], fa8[j2][i], acc[i][j], 0, 0, 0,
+                                                                                    0x7F7F7F7F, 0, 0x7F7F7F7F);
+            // pin this step's MFMAs here: left alone, the compiler sinks the (pure) MFMA calls of up to 17 K-steps to the
+            // end of the tap loop and keeps all their fragments live -- 512 VGPRs + scratch, 1 workgroup per CU (3x slower)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc[i][j]));
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < (F8 ? 1 : 4); ++kk)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -589,7 +679,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     constexpr int CG = BN / 8;
     constexpr int PASSES = BM * CG / NT;
     static_assert(PASSES * NT == BM * CG, "epilogue split");
-    size_t e_off[PASSES];
+    size_t e_off[PASSES], e_off8[PASSES];
     uint4 e_res[PASSES];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -597,6 +687,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         const int r = idx / CG, cg = idx - r * CG;
         const int oy = y0 + r / TW, ox = x0 + r % TW;
         e_off[ps] = (((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.ygs + n0 + cg * 8;
+        e_off8[ps] = (((size_t)img * p.H + oy) * p.W + ox) * p.y8cs + (size_t)g * p.Cout + n0 + cg * 8;
     }
     if (p.res) {                                   // all residual loads in flight together, under the LDS staging
 #pragma unroll
@@ -634,16 +725,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.y_f32) {
-            float* yo = reinterpret_cast<float*>(p.y) + e_off[ps];
-            *reinterpret_cast<f32x4_t*>(yo) = f32x4_t{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4_t*>(yo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
-        } else {
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + e_off[ps]) = o;
-        }
+        store_out8(p, v, e_off[ps], e_off8[ps]);
     }
     dbg_stamp(p, 3);
 #endif
@@ -981,17 +1063,18 @@ int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
 }
 
 int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.ks != 3 || a.stride != 1 || a.Cin != 64 || a.Cout != 64 || a.H % 4 != 0 || a.W % 16 != 0 || a.ygs != 64) return W2C_E_ARG;
+    if (a.ks != 3 || a.stride != 1 || a.Cin != 64 || a.Cout != 64 || a.H % 4 != 0 || a.W % 16 != 0 || a.ygs != 64 || a.y8 || !a.y) return W2C_E_ARG;
     if ((size_t)a.M * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.M * a.H * a.W * a.ycs * 2 >= (1ull << 31)) return W2C_E_ARG;
     return a.res ? launch_regw<true>(a, groups, s) : launch_regw<false>(a, groups, s);
 }
 
 
-template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2, bool F8 = false>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
+    constexpr int CK = OpT<F8>::CK;
+    if (a.ks != 3 || a.stride != 1 || a.Cin % CK != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
         return W2C_E_ARG;
-    if (PB == 1 && a.Cin != 64) return W2C_E_ARG;
+    if (PB == 1 && a.Cin != CK) return W2C_E_ARG;
     a.ntm = a.M * (a.H / TH) * (a.W / TW);
     a.ntn = a.Cout / BN;
     constexpr int ring = PB * (TH + 2) * (TW + 2) * 128 + STAGES * BN * 128;
@@ -1002,12 +1085,12 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -1092,7 +1175,8 @@ int launch_conv_splitk(ConvArgs& a, int groups, int ksplit, hipStream_t s) {
 }
 
 // tile shape + split count for a split-K launch; ksplit == 1 means "not worth splitting".
-// The split count is a function of the LAYER (channels, taps, output map size) only, never of the image count M: the
+// The split count is a function of the LAYER (channels, taps, output map size) only, never of the image count M or of the
+// number of groups launched together: the
 // partial sums of a split are added in split order, so a split that moved with M would make a shard of the agents
 // round differently from the unsharded batch.  It is sized for a nominal 16-image batch (~2 workgroups per CU, >= 3
 // K-steps per split); other batch sizes get the same arithmetic with more or fewer workgroups.
@@ -1106,7 +1190,8 @@ SplitPlan plan_splitk(const ConvArgs& a, int groups, int want) {
     int ks = want;
     if (ks <= 0) {
         const long rows16 = 16L * a.Ho * a.Wo;
-        const long tiles16 = ((rows16 + sp.bm - 1) / sp.bm) * (a.Cout / sp.bn) * groups;
+        const long tiles16 = ((rows16 + sp.bm - 1) / sp.bm) * (a.Cout / sp.bn);     // per group: running two trunks side by
+                                                                                     // side or one at a time rounds alike
         ks = (int)((512 + tiles16 - 1) / tiles16);
         if (ks > kt / 3) ks = kt / 3;
         if (tiles16 >= 256) ks = 1;
@@ -1117,10 +1202,11 @@ SplitPlan plan_splitk(const ConvArgs& a, int groups, int want) {
     return sp;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int STAGES>
+template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool F8 = false>
 int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.Cin % BK != 0 || a.Cout % BN != 0) return W2C_E_ARG;
-    a.cin_tiles = a.Cin / BK;
+    constexpr int CK = OpT<F8>::CK;
+    if (a.Cin % CK != 0 || a.Cout % BN != 0) return W2C_E_ARG;
+    a.cin_tiles = a.Cin / CK;
     a.ktiles = a.ks * a.ks * a.cin_tiles;
     a.ntm = (a.rows + BM - 1) / BM;
     a.ntn = a.Cout / BN;
@@ -1131,12 +1217,12 @@ int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -1163,6 +1249,35 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
     }
 }
 
+// fp8 (e4m3, MX-scaled K=64 MFMA) siblings: identical byte geometry -- a K-step is still one 128-byte run per row, now
+// 128 channels -- so the same tile shapes apply with half the K-steps.
+int launch_variant_f8(int variant, ConvArgs& a, int groups, hipStream_t s) {
+    switch (variant) {
+        case 0: return launch_conv<128, 128, 2, 2, 64, 2, true>(a, groups, s);
+        case 3: return launch_conv<128, 64, 2, 2, 64, 2, true>(a, groups, s);
+        case 6: return launch_conv<64, 64, 2, 2, 64, 2, true>(a, groups, s);
+        case 30: return launch_patch<8, 16, 128, 2, 2, 2, 2, true>(a, groups, s);
+        case 36: return launch_patch<8, 16, 64, 4, 2, 3, 2, true>(a, groups, s);
+        case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1, true>(a, groups, s);      // Cin == 128: one chunk
+        case 40: return launch_patch<8, 16, 128, 2, 2, 2, 1, true>(a, groups, s);     // Cin == 128, 128 channels per tile
+        default: return W2C_E_ARG;
+    }
+}
+
+int pick_variant_f8(const ConvArgs& a, int groups) {
+    const long rows = a.rows;
+    const int Cout = a.Cout;
+    if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
+        const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
+        if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 40;
+        if (a.Cin == 128 && Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 38;
+        if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;
+    }
+    if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return 0;
+    if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
+    return 6;
+}
+
 // Per-layer kernel choice, from the per-layer sweeps of tools/bench_conv.py on MI355X
 // (profiles/r01_b_conv_variant_sweep.txt; run-to-run noise of single cells is ~+-8 %).  Stride-1 3x3 convs go to
 // the patch-staged kernel with 128-pixel (8x16) tiles sized so that >= 2 workgroups share a CU:
@@ -1179,7 +1294,7 @@ int pick_variant(const ConvArgs& a, int groups) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
         // layer1 at full size: weights stationary in registers (v50) once every wave of the chip gets >= 4 tiles
         // (its 7 us weight prologue is per launch); smaller problems stay on the ring kernel
-        if (a.Cin == 64 && Cout == 64 && a.ygs == 64 && a.H % 4 == 0 && !a.y_f32 && (long)a.M * (a.H / 4) * (a.W / 16) * groups >= 4096 &&
+        if (a.Cin == 64 && Cout == 64 && a.ygs == 64 && a.H % 4 == 0 && !a.y_f32 && !a.y8 && a.y && (long)a.M * (a.H / 4) * (a.W / 16) * groups >= 4096 &&
             (size_t)a.M * a.H * a.W * a.xcs * 2 < (1ull << 31) && (size_t)a.M * a.H * a.W * a.ycs * 2 < (1ull << 31))
             return 50;
         if (a.Cin == 64 && Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 38;
@@ -1192,28 +1307,32 @@ int pick_variant(const ConvArgs& a, int groups) {
     return 8;
 }
 
-int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
-              const uint16_t* w, int Cout, int ksize, int stride, int groups,
+int fill_args(ConvArgs& a, const void* x, int M, int H, int W, int Cin, int x_cstride,
+              const void* w, int Cout, int ksize, int stride, int groups,
               const float* scale, const float* shift, const uint16_t* residual, int relu,
-              void* y, int y_cstride, int y_is_f32, const void* zero_page, long long y_group_stride) {
-    if (!x || !w || !scale || !shift || !y || !zero_page) return W2C_E_ARG;
+              void* y, int y_cstride, int y_is_f32, const void* zero_page, long long y_group_stride, bool f8 = false,
+              uint8_t* y8 = nullptr, int y8_cstride = 0, float y8_scale = 1.f) {
+    const int es = f8 ? 1 : 2, ck = f8 ? 128 : 64;
+    if (!x || !w || !scale || !shift || (!y && !y8) || !zero_page) return W2C_E_ARG;
     if (M <= 0 || H <= 0 || W <= 0 || groups <= 0) return W2C_E_ARG;
-    if (Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 32) != 0) return W2C_E_ARG;
+    if (Cin <= 0 || (Cin % ck) != 0 || Cout <= 0 || (Cout % 32) != 0) return W2C_E_ARG;
     if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return W2C_E_ARG;
     if (y_group_stride == 0) y_group_stride = Cout;
-    if (x_cstride < groups * Cin || y_cstride < (y_group_stride == Cout ? groups : 1) * Cout) return W2C_E_ARG;
-    if ((x_cstride % 8) != 0 || (y_cstride % 8) != 0 || (y_group_stride % 8) != 0) return W2C_E_ARG;   // 16-byte vector access
-    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    if (x_cstride < groups * Cin || ((y || residual) && y_cstride < (y_group_stride == Cout ? groups : 1) * Cout)) return W2C_E_ARG;
+    if ((x_cstride * es % 16) != 0 || ((y || residual) && (y_cstride % 8) != 0) || (y_group_stride % 8) != 0) return W2C_E_ARG;   // 16-byte vector access
+    if (y8 && (y8_cstride < groups * Cout || (y8_cstride % 8) != 0 || !(y8_scale > 0.f))) return W2C_E_ARG;
+    a.x = reinterpret_cast<const uint16_t*>(x); a.w = reinterpret_cast<const uint16_t*>(w);
+    a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.zeros = reinterpret_cast<const uint16_t*>(zero_page);
     a.M = M; a.H = H; a.W = W; a.Cin = Cin; a.xcs = x_cstride;
     a.ks = ksize; a.stride = stride; a.pad = ksize == 3 ? 1 : 0;
     a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
     a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
-    a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;
+    a.Cout = Cout; a.ycs = y_cstride; a.relu = relu; a.y_f32 = y_is_f32;      // ycs is also the residual's pixel stride
     // the kernels address x and w through buffer descriptors with 32-bit byte offsets (extent < 2 GiB; an offset of
     // 0x80000000 is the "padding -> zeros" marker) and count output rows in an int: refuse what would overflow
     // instead of silently reading zeros.  Callers chunk M (ops.conv_igemm does).
-    if ((size_t)M * H * W * x_cstride * 2 >= (1ull << 31) || (size_t)Cout * ksize * ksize * Cin * 2 >= (1ull << 31) ||
+    if ((size_t)M * H * W * x_cstride * es >= (1ull << 31) || (size_t)Cout * ksize * ksize * Cin * es >= (1ull << 31) ||
         (size_t)M * a.Ho * a.Wo >= (1ull << 29))
         return W2C_E_ARG;
     a.rows = M * a.Ho * a.Wo;
@@ -1221,6 +1340,7 @@ int fill_args(ConvArgs& a, const uint16_t* x, int M, int H, int W, int Cin, int 
     a.ws = nullptr;
     a.n_split = 1;
     a.ygs = y_group_stride;
+    a.y8 = y8; a.y8cs = y8_cstride; a.q8 = y8 ? 1.f / y8_scale : 1.f;
     return W2C_OK;
 }
 
@@ -1300,4 +1420,52 @@ extern "C" int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int 
     a.dbg = g_dbg_next;
     g_dbg_next = nullptr;
     return launch_variant(variant, a, groups, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int w2c_conv_igemm_fp8(const void* x, int x_is_fp8, int M, int H, int W, int Cin, int x_cstride,
+                                  const void* w, int Cout, int ksize, int stride, int groups,
+                                  const float* scale, const float* shift,
+                                  const uint16_t* residual, int relu,
+                                  uint16_t* y_bf16, int y_cstride, long long y_group_stride,
+                                  uint8_t* y_fp8, int y8_cstride, float y8_scale,
+                                  const void* zero_page, int variant, w2c_stream_t stream) {
+    w2c_clear_error();
+    ConvArgs a;
+    int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w, Cout, ksize, stride, groups, scale, shift, residual, relu,
+                       y_bf16, y_cstride, 0, zero_page, y_group_stride, x_is_fp8 != 0, y_fp8, y8_cstride, y8_scale);
+    if (rc != W2C_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (x_is_fp8) return launch_variant_f8(variant >= 0 ? variant : pick_variant_f8(a, groups), a, groups, s);
+    return launch_variant(variant >= 0 ? variant : pick_variant(a, groups), a, groups, s);
+}
+
+// One wave: C[32][32] (f32, row-major) = A[32][64] * B[32][64]^T with e4m3 operands through the MX-scaled MFMA with unit
+// block scales -- the primitive the fp8 conv kernels are built on (unit test of the fragment convention).
+__global__ void mx_mfma_probe_kernel(const uint8_t* A, const uint8_t* B, float* C) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+    const u32x4_t* ap = reinterpret_cast<const u32x4_t*>(A + l31 * 64 + lhi * 32);
+    const u32x4_t* bp = reinterpret_cast<const u32x4_t*>(B + l31 * 64 + lhi * 32);
+    f32x16_t acc;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat_i32x8(ap[0], ap[1]), cat_i32x8(bp[0], bp[1]), acc, 0, 0, 0,
+                                                          0x7F7F7F7F, 0, 0x7F7F7F7F);
+    for (int e = 0; e < 16; ++e) C[((e & 3) + 8 * (e >> 2) + 4 * lhi) * 32 + l31] = acc[e];    // D[row of A][row of B]
+#endif
+}
+__global__ void fp8_pack_probe_kernel(const float* x, uint8_t* y, int n) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<uint32_t*>(y + i) = pack_fp8x4(x[i], x[i + 1], x[i + 2], x[i + 3]);
+}
+extern "C" int w2c_debug_mx_mfma(const uint8_t* a, const uint8_t* b, float* c, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!a || !b || !c) return W2C_E_ARG;
+    hipLaunchKernelGGL(mx_mfma_probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), a, b, c);
+    return w2c_launch_status();
+}
+extern "C" int w2c_debug_fp8_pack(const float* x, uint8_t* y, int n, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !y || n <= 0 || (n & 3)) return W2C_E_ARG;
+    hipLaunchKernelGGL(fp8_pack_probe_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n);
+    return w2c_launch_status();
 }

@@ -133,10 +133,11 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
                 const bool ok = g4[e] >= 0 && g4[e] < ncls;
                 const int bin = ok ? (int)g4[e] * ncls + bi[e] : -1;
                 const int first = __builtin_amdgcn_readfirstlane(bin);
-                if (__builtin_amdgcn_ballot_w64(bin == first) == __builtin_amdgcn_ballot_w64(true)) {
+                const unsigned long long act = __builtin_amdgcn_ballot_w64(true);      // taken BEFORE the one-lane branch
+                if (__builtin_amdgcn_ballot_w64(bin == first) == act) {
                     // the whole wave (its active lanes) in one bin: one atomic for all of them
-                    if (first >= 0 && (int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
-                        atomicAdd(&lh[first], (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+                    if (first >= 0 && (int)(threadIdx.x & 63) == __builtin_ctzll(act))
+                        atomicAdd(&lh[first], (unsigned)__builtin_popcountll(act));
                 } else if (ok) {
                     atomicAdd(&lh[bin], 1u);
                 }

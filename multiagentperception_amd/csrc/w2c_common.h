@@ -28,6 +28,23 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, w2c_bf16x2_t));
 }
 
+// fp8 (OCP e4m3fn, gfx950's native format) pack of four f32: v_cvt_pk_fp8_f32 rounds to nearest even; inputs are clamped
+// to the format's finite range first (+-448) so an out-of-range activation saturates instead of becoming NaN.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+    b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f);
+    d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+__device__ __forceinline__ i32x8_t cat_i32x8(u32x4_t lo, u32x4_t hi) {
+    return i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
+
 // Last HIP error text of the calling thread (for w2c_last_error_string()).
 inline char* w2c_errbuf() {
     static thread_local char buf[256] = {0};

@@ -76,18 +76,73 @@ class ConvPlan:
         self.scale = torch.cat(scs).contiguous()
         self.shift = torch.cat(shs).contiguous()
 
-    def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None):
+    def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None, out=None, out_ch_off=0):
         # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
                               self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,
-                              ksplit=None if os.environ.get('W2C_NO_SPLITK') else 0, out_groups=out_groups)
+                              ksplit=None if os.environ.get('W2C_NO_SPLITK') else 0, out_groups=out_groups, out=out,
+                              out_ch_off=out_ch_off)
+
+
+FP8_HEADROOM = 256.0       # calibrated amax of an fp8 tensor maps to 256: ~0.8 binade below e4m3's 448 before saturation
+
+
+class Fp8ConvPlan:
+    """One w2c_conv_igemm_fp8 call.  Operands: fp8 e4m3 (`in_scale` = the input tensor's quantisation step; weights
+    quantised per OUTPUT CHANNEL, w8 = e4m3(w / sw[co]), sw[co] = max|w[co]| / 448) or bf16 (in_scale None: a bf16
+    tensor producing an fp8 one).  All scales are folded into the f32 epilogue: y = act(acc * (bn_scale*sw*in_scale) +
+    shift + residual); an fp8 output is e4m3(y / out_scale)."""
+
+    def __init__(self, convs, bns, relu=True, in_scale=None):
+        c0 = convs[0]
+        self.groups, self.cin, self.cout = len(convs), c0.in_channels, c0.out_channels
+        self.ksize, self.stride, self.relu = c0.kernel_size[0], c0.stride[0], relu
+        self.fp8_in = in_scale is not None
+        ws, scs, shs = [], [], []
+        for c, bn in zip(convs, bns):
+            w = c.weight.detach().float().permute(0, 2, 3, 1).reshape(c.out_channels, -1)       # [Cout, k*k*Cin]
+            sc, sh = _fold_bn(bn, c.bias)
+            if self.fp8_in:
+                sw = w.abs().amax(dim=1).clamp_min(1e-30) / ops.FP8_MAX
+                ws.append((w / sw[:, None]).to(ops.FP8).view(torch.uint8))
+                sc = sc * sw * float(in_scale)
+            else:
+                ws.append(w.to(BF16))
+            scs.append(sc)
+            shs.append(sh)
+        self.w = torch.stack(ws, 0).contiguous()
+        self.scale = torch.cat(scs).contiguous()
+        self.shift = torch.cat(shs).contiguous()
+
+    def run(self, x, x_ch_off=0, residual=None, out_bf16=True, out_fp8_scale=None, out_groups=None, out=None, out_ch_off=0):
+        return ops.conv_fp8(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups, self.scale,
+                            self.shift, residual=residual, relu=self.relu, out_bf16=out_bf16, out_fp8_scale=out_fp8_scale,
+                            out_groups=out_groups, out=out, out_ch_off=out_ch_off)
 
 
 class TrunkPlan:
-    """G ResNet-18 trunks + squeezers run side by side (G = 1 for Single_agent, 2 for MIMOcom*)."""
+    """G ResNet-18 trunks + squeezers run side by side (G = 1 for Single_agent, 2 for MIMOcom*).
 
-    def __init__(self, encoders):
+    precision="fp8" (BASELINE.json configs[4]): layer2..layer4 and the squeezer of the VALUE encoder (encoders[0]:
+    u_encoder / Single_agent.encoder) run on fp8 e4m3 operands (MX-scaled MFMA, 2x the bf16 rate).  The policy encoder
+    (encoders[1], query_key_net.img_encoder) stays bf16: its output feeds a softmax over scores of magnitude ~10-30, which
+    turns e4m3's 2^-4 relative rounding into O(0.2-0.35) errors of the communication graph P (measured with precision
+    "fp8-all", which quantises both trunks; profiles/r02_fp8_parity.txt) -- the graph is the method's point, so it keeps
+    the bf16 path's accuracy.  The stem, layer1, everything after the squeezers and every residual path stay bf16:
+      layer2.0.conv1 / downsample read layer1's bf16 output (Cin = 64 is below the fp8 kernels' 128-channel K-step);
+      every BasicBlock output is written twice -- bf16 (the next block's identity) and fp8 (the next conv's operand);
+      conv1 outputs exist only as fp8; the squeezers read fp8 and write bf16.
+    Per-tensor activation scales come from ONE calibration pass of the bf16 path (amax of each tensor, both trunks
+    together) on the first batch the plan sees (or an explicit calibrate()); weights are scaled per output channel."""
+
+    def __init__(self, encoders, precision="bf16"):
+        if precision not in ("bf16", "fp8", "fp8-all"):
+            raise ops.W2CError("trunk precision %r: 'bf16', 'fp8' (value encoder) or 'fp8-all' (both encoders)" % (precision,))
+        self.precision = precision
+        self.fp8 = None                      # built by calibrate(): per-block Fp8ConvPlans + scales
         self.G = len(encoders)
+        self.n8 = 0 if precision == "bf16" else (1 if precision == "fp8" else self.G)     # leading trunks that run in fp8
+        self._encoders = encoders if self.n8 else None
         fbs = [e.feature_backbone.feature_backbone for e in encoders]
         # stem: [Cout][7][8][4] bf16, kx==7 / ci==3 zero
         ws, scs, shs = [], [], []
@@ -126,11 +181,118 @@ class TrunkPlan:
         """layer1..4 + squeezers on the pooled stem output -> bf16 NHWC [N*B, H/32, W/32, G*feat]; with
         squeezer_out = one [N*B, H/32, W/32, feat] tensor per trunk, each squeezer writes its own (the agent-parallel
         path: V lands in the rank's slot of the all-gather buffer) and the list is returned."""
+        if self.n8:
+            if self.fp8 is None:
+                self.calibrate(p)
+            return self._after_stem_fp8(p, squeezer_out)
         for c1, c2, ds in self.blocks:
             t = c1.run(p)
             idt = p if ds is None else ds.run(p)
             p = c2.run(t, residual=idt)
         return self.squeezer.run(p, out_groups=squeezer_out)
+
+    # ---- fp8 trunk (cfg 5) ------------------------------------------------------------------------------------------
+    def calibrate(self, p, reduce_amax=None):
+        """One bf16 pass over the pooled stem output `p`: records amax of every tensor that will live in fp8 (conv1
+        outputs and block outputs of layer2..4 of the fp8 trunks) and builds the fp8 plans (+ single-trunk bf16 plans for
+        the trunks that stay bf16).  reduce_amax: optional callable applied to the amax vector (agent-parallel ranks
+        pass an all-reduce MAX so every rank quantises alike)."""
+        n8, G = self.n8, self.G
+        amax = []
+        q = p
+        for bi, (c1, c2, ds) in enumerate(self.blocks):
+            t = c1.run(q)
+            idt = q if ds is None else ds.run(q)
+            q = c2.run(t, residual=idt)
+            if bi >= 2:
+                c = t.shape[3] // G * n8                                         # channels of the fp8 trunks (they come first)
+                amax += [t[..., :c].float().amax(), q[..., :c].float().amax()]
+        amax = torch.stack(amax)
+        if reduce_amax is not None:
+            amax = reduce_amax(amax)
+        steps = (amax.clamp_min(1e-6) / FP8_HEADROOM).tolist()                  # quantisation step of each fp8 tensor
+        fbs = [e.feature_backbone.feature_backbone for e in self._encoders]
+        f8, b16 = fbs[:n8], fbs[n8:]
+        plans, rest, in_step, k = [], [], None, 0
+        for li in (2, 3, 4):
+            for bi in (0, 1):
+                blks = [getattr(fb, "layer%d" % li)[bi] for fb in f8]
+                t_step, o_step = steps[k], steps[k + 1]
+                k += 2
+                c1 = Fp8ConvPlan([b.conv1 for b in blks], [b.bn1 for b in blks], relu=True, in_scale=in_step)
+                c2 = Fp8ConvPlan([b.conv2 for b in blks], [b.bn2 for b in blks], relu=True, in_scale=t_step)
+                ds = None
+                if blks[0].downsample is not None:
+                    ds = Fp8ConvPlan([b.downsample[0] for b in blks], [b.downsample[1] for b in blks], relu=False,
+                                     in_scale=in_step)
+                plans.append((c1, c2, ds, t_step, o_step))
+                in_step = o_step
+                if b16:
+                    bl = [getattr(fb, "layer%d" % li)[bi] for fb in b16]
+                    rest.append((ConvPlan([b.conv1 for b in bl], [b.bn1 for b in bl], relu=True),
+                                 ConvPlan([b.conv2 for b in bl], [b.bn2 for b in bl], relu=True),
+                                 None if bl[0].downsample is None else
+                                 ConvPlan([b.downsample[0] for b in bl], [b.downsample[1] for b in bl], relu=False)))
+        sq = [e.squeezer.cbr_unit for e in self._encoders]
+        self.fp8 = dict(blocks=plans, steps=steps, rest=rest,
+                        squeezer=Fp8ConvPlan([u[0] for u in sq[:n8]], [u[1] for u in sq[:n8]], relu=True, in_scale=in_step),
+                        rest_squeezer=ConvPlan([u[0] for u in sq[n8:]], [u[1] for u in sq[n8:]], relu=True) if b16 else None)
+
+    def _after_stem_fp8(self, p, squeezer_out=None):
+        n8, G = self.n8, self.G
+        for c1, c2, ds in self.blocks[:2]:                                      # layer1: bf16, all trunks side by side
+            t = c1.run(p)
+            p = c2.run(t, residual=p)
+        feat = self.fp8["squeezer"].cout
+        if squeezer_out is None:
+            M, H4, W4, _ = p.shape
+            sq = torch.empty((M, H4 // 8, W4 // 8, G * feat), dtype=BF16, device=p.device)
+        # The two halves below are independent until the squeezers: the bf16 half runs on a side stream (a parallel
+        # branch when the forward is captured into a HIP graph), so its half-size launches fill the CUs the fp8 half
+        # leaves idle (320-640 workgroups per launch on 512 slots).
+        main = torch.cuda.current_stream(p.device)
+        side = self._side_stream(p.device) if (self.fp8["rest"] and not os.environ.get("W2C_FP8_SERIAL")) else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._rest_bf16(p, sq if squeezer_out is None else None, squeezer_out, feat)
+        # ---- fp8 trunks (channels [0, 64*n8) of layer1's output) ----
+        x16, x8 = p, None
+        nb = len(self.fp8["blocks"])
+        for i, (c1, c2, ds, t_step, o_step) in enumerate(self.fp8["blocks"]):
+            src = x16 if x8 is None else x8                                      # layer2.0 reads layer1's bf16 output
+            _, t8 = c1.run(src, out_bf16=False, out_fp8_scale=t_step)
+            idt = x16 if ds is None else ds.run(src)[0]
+            x16, x8 = c2.run(t8, residual=idt, out_bf16=(i + 1 < nb), out_fp8_scale=o_step)
+        if squeezer_out is not None:
+            self.fp8["squeezer"].run(x8, out_groups=squeezer_out[:n8])
+        else:
+            self.fp8["squeezer"].run(x8, out=sq, out_ch_off=0)
+        if side is not None:
+            main.wait_stream(side)
+        elif self.fp8["rest"]:
+            self._rest_bf16(p, sq if squeezer_out is None else None, squeezer_out, feat)
+        return list(squeezer_out) if squeezer_out is not None else sq
+
+    def _side_stream(self, dev):
+        st = self.__dict__.setdefault("_side", {})
+        if dev not in st:
+            st[dev] = torch.cuda.Stream(device=dev)
+        return st[dev]
+
+    def _rest_bf16(self, p, sq, squeezer_out, feat):
+        """the trunks that stay bf16 (the policy encoder): same blocks, one group each launch, reading their slice of
+        layer1's output; squeezer into channels [n8*feat, ...) of sq (or into squeezer_out[n8:])."""
+        n8 = self.n8
+        q, off = p, 64 * n8
+        for c1, c2, ds in self.fp8["rest"]:
+            t = c1.run(q, x_ch_off=off)
+            idt = ds.run(q, x_ch_off=off) if ds is not None else q
+            q, off = c2.run(t, residual=idt), 0
+        if squeezer_out is not None:
+            self.fp8["rest_squeezer"].run(q, out_groups=squeezer_out[n8:])
+        else:
+            self.fp8["rest_squeezer"].run(q, out=sq, out_ch_off=n8 * feat)
 
     def run(self, x, n_agents):
         """x f32 [B, 3N, H, W] -> bf16 NHWC [N*B, H/32, W/32, G*feat] (squeezer outputs side by side)."""
@@ -218,7 +380,8 @@ class CommEngine:
         self.who = bool(model.attention_net.who)
         self.has_query = bool(model.has_query)
         self.n_classes = model.n_classes
-        self.trunk = TrunkPlan([model.u_encoder, model.query_key_net.img_encoder])
+        self.trunk = TrunkPlan([model.u_encoder, model.query_key_net.img_encoder],
+                               precision=getattr(model, "trunk_precision", "bf16"))
         pn = model.query_key_net
         self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
                        for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
@@ -331,7 +494,7 @@ class CommEngine:
 class SingleEngine:
     def __init__(self, model):
         self.n_classes = model.n_classes
-        self.trunk = TrunkPlan([model.encoder])
+        self.trunk = TrunkPlan([model.encoder], precision=getattr(model, "trunk_precision", "bf16"))
         self.decoder = DecoderPlan(model.decoder, self.n_classes)
 
     def forward(self, x):

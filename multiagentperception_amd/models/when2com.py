@@ -41,6 +41,18 @@ class _EngineCacheMixin:
         self._engines.clear()
         return super()._apply(fn, *a, **k)
 
+    trunk_precision = "bf16"
+
+    def set_trunk_precision(self, precision):
+        """'bf16' (default), 'fp8' (value encoder's layer2..4 + squeezer convs on fp8 e4m3 MFMA; the policy encoder that
+        drives the communication graph stays bf16) or 'fp8-all' (both encoders; for measurement) -- BASELINE.json
+        configs[4], see engine.TrunkPlan.  Not part of the reference API.  Drops the packed weights."""
+        if precision not in ("bf16", "fp8", "fp8-all"):
+            raise ValueError("trunk precision must be 'bf16', 'fp8' or 'fp8-all'")
+        self.trunk_precision = precision
+        self._engines.clear()
+        return self
+
     def _engine_for(self, x, factory):
         if not x.is_cuda:
             raise W2CError("%s.forward (eval) runs only on an MI355X device tensor; got input on %s. "

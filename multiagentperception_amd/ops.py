@@ -164,7 +164,8 @@ _MAX_X_BYTES = (1 << 31) - 1       # the conv kernels address x through a 32-bit
 
 
 def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
-               out=None, out_f32=False, out_cstride=None, variant=None, ksplit=None, out_groups=None, _gstride=0):
+               out=None, out_f32=False, out_cstride=None, variant=None, ksplit=None, out_groups=None, _gstride=0,
+               out_ch_off=0):
     """x: bf16 NHWC [M,H,W,xcs]; the conv reads channels [x_ch_off + g*cin, ...).  Returns/accepts
     out NHWC [M,Ho,Wo,out_cstride] (bf16, or f32 when out_f32).  ksplit: None = one workgroup per tile;
     0 = split-K chosen by the library for tail layers; n = forced n-way split.
@@ -200,6 +201,10 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     Wo = (W + 2 * pad - ksize) // stride + 1
     if out_cstride is None:
         out_cstride = groups * cout
+    if out_ch_off:                                   # write channels [out_ch_off, +groups*cout) of a wider `out` tensor
+        if out is None or residual is not None or out_ch_off < 0 or out_ch_off % 8 or out_ch_off + groups * cout > out.shape[3]:
+            raise W2CError("conv: out_ch_off needs an `out` tensor wide enough, no residual, a multiple of 8")
+        out_cstride = out.shape[3]
     if out_cstride < (groups if not _gstride else 1) * cout:
         raise W2CError("conv: out_cstride %d too small for %d x %d output channels" % (out_cstride, groups, cout))
     if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
@@ -217,9 +222,11 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
             hi = min(M, lo + step)
             conv_igemm(x[lo:hi], x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift,
                        residual=None if residual is None else residual[lo:hi], relu=relu, out=out[lo:hi],
-                       out_f32=out_f32, out_cstride=out_cstride, variant=variant, ksplit=ksplit, _gstride=_gstride)
+                       out_f32=out_f32, out_cstride=out_cstride, variant=variant, ksplit=ksplit, _gstride=_gstride,
+                       out_ch_off=out_ch_off)
         return out
     xptr = x.data_ptr() + 2 * x_ch_off
+    optr = out.data_ptr() + (4 if out_f32 else 2) * out_ch_off
     timer = getattr(_tls, "conv_timer", None)
     if timer is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -235,19 +242,19 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
             ws = splitk_workspace(dev, ws_bytes)
             check(_native.lib().w2c_conv_igemm_bf16_splitk(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride,
                                                            groups, _p(scale), _p(shift), _p(residual),
-                                                           1 if relu else 0, _p(out), out_cstride,
+                                                           1 if relu else 0, optr, out_cstride,
                                                            1 if out_f32 else 0, _p(zero_page(dev)), int(ksplit),
                                                            _p(ws), ws.numel(), int(_gstride), _stream(dev)),
                   "w2c_conv_igemm_bf16_splitk")
         elif variant is None:
             check(_native.lib().w2c_conv_igemm_bf16(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride, groups,
                                                     _p(scale), _p(shift), _p(residual), 1 if relu else 0,
-                                                    _p(out), out_cstride, 1 if out_f32 else 0,
+                                                    optr, out_cstride, 1 if out_f32 else 0,
                                                     _p(zero_page(dev)), int(_gstride), _stream(dev)), "w2c_conv_igemm_bf16")
         else:
             check(_native.lib().w2c_conv_igemm_bf16_variant(xptr, M, H, W, cin, xcs, _p(w_packed), cout, ksize, stride,
                                                             groups, _p(scale), _p(shift), _p(residual),
-                                                            1 if relu else 0, _p(out), out_cstride,
+                                                            1 if relu else 0, optr, out_cstride,
                                                             1 if out_f32 else 0, _p(zero_page(dev)), int(variant),
                                                             int(_gstride), _stream(dev)), "w2c_conv_igemm_bf16_variant(%d)" % variant)
     if timer is not None:
@@ -257,6 +264,78 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
                   + (M * Ho * Wo * cout * groups * 2 if residual is not None else 0) + groups * cout * ksize * ksize * cin * 2)
         timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups), nbytes))
     return out
+
+
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def conv_fp8(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shift, residual=None, relu=True,
+             out_bf16=True, out_fp8_scale=None, out_groups=None, variant=-1, out=None, out_ch_off=0):
+    """The conv with fp8 (e4m3) operands when x is a uint8 tensor [M,H,W,xcs] of e4m3 bytes (w_packed uint8
+    [G,Cout,k*k*cin]), or with bf16 operands when x is bf16 -- either way able to emit a bf16 result, an fp8 result
+    (e4m3(result / out_fp8_scale), uint8 [M,Ho,Wo,G*cout]) or both.  Returns (y_bf16 | None | list (out_groups),
+    y_fp8 | None).  Scales: the caller folds weight / input scales into `scale` (include/w2c_hip.h)."""
+    dev = _need_gpu(x, w_packed, scale, shift, residual)
+    f8 = x.dtype == torch.uint8
+    if not f8 and x.dtype != BF16:
+        raise W2CError("conv_fp8: x must be uint8 (e4m3 bytes) or bf16")
+    if w_packed.dtype != (torch.uint8 if f8 else BF16):
+        raise W2CError("conv_fp8: weights must have the operand type of x")
+    M, H, W, xcs = x.shape
+    pad = 1 if ksize == 3 else 0
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
+        raise W2CError("conv_fp8: channels [%d, %d) outside the tensor's %d channels" % (x_ch_off, x_ch_off + groups * cin, xcs))
+    y, gstride, ycs = None, 0, groups * cout
+    if out_groups is not None:
+        g0 = out_groups[0]
+        _need_gpu(*out_groups)
+        if len(out_groups) != groups or any(t.shape != g0.shape or t.dtype != BF16 for t in out_groups) or \
+                tuple(g0.shape[:3]) != (M, Ho, Wo) or g0.shape[3] < cout:
+            raise W2CError("conv_fp8: bad out_groups")
+        if groups > 1:
+            gstride = (out_groups[1].data_ptr() - g0.data_ptr()) // 2
+            if any(t.data_ptr() - g0.data_ptr() != 2 * i * gstride for i, t in enumerate(out_groups)) or gstride % 8 or gstride == 0:
+                raise W2CError("conv_fp8: out_groups tensors must be evenly spaced, 16-byte aligned")
+        y, ycs = g0, g0.shape[3]
+    elif out is not None:                       # write channels [out_ch_off, out_ch_off + groups*cout) of a wider bf16 tensor
+        _need_gpu(out)
+        if out.dtype != BF16 or tuple(out.shape[:3]) != (M, Ho, Wo) or out_ch_off < 0 or out_ch_off % 8 or \
+                out_ch_off + groups * cout > out.shape[3] or residual is not None:
+            raise W2CError("conv_fp8: bad out / out_ch_off")
+        y, ycs = out, out.shape[3]
+    elif out_bf16:
+        y = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    y8 = None
+    if out_fp8_scale is not None:
+        y8 = torch.empty((M, Ho, Wo, groups * cout), dtype=torch.uint8, device=dev)
+    if y is None and y8 is None:
+        raise W2CError("conv_fp8: no output requested")
+    if residual is not None and (residual.dtype != BF16 or tuple(residual.shape) != (M, Ho, Wo, groups * cout)
+                                 or out_groups is not None):
+        raise W2CError("conv_fp8: residual must be bf16 [M,Ho,Wo,groups*cout] (and excludes out_groups)")
+    timer = getattr(_tls, "conv_timer", None)
+    if timer is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+    es = 1 if f8 else 2
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_igemm_fp8(x.data_ptr() + es * x_ch_off, 1 if f8 else 0, M, H, W, cin, xcs, _p(w_packed),
+                                               cout, ksize, stride, groups, _p(scale), _p(shift), _p(residual),
+                                               1 if relu else 0, (_p(y) + 2 * out_ch_off) if y is not None else 0, ycs,
+                                               int(gstride), _p(y8), groups * cout,
+                                               float(out_fp8_scale) if out_fp8_scale is not None else 1.0,
+                                               _p(zero_page(dev)), int(variant), _stream(dev)), "w2c_conv_igemm_fp8")
+    if timer is not None:
+        ev1.record(torch.cuda.current_stream(dev))
+        flops = 2.0 * M * Ho * Wo * cout * (ksize * ksize * cin) * groups
+        nbytes = (M * H * W * cin * groups * es + M * Ho * Wo * cout * groups * ((2 if y is not None else 0) + (1 if y8 is not None else 0))
+                  + (M * Ho * Wo * cout * groups * 2 if residual is not None else 0) + groups * cout * ksize * ksize * cin * es)
+        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups, "fp8" if f8 else "bf16>fp8"), nbytes))
+    return (list(out_groups) if out_groups is not None else y), y8
 
 
 def linear(x, w, b, relu, x_stride=None, rows=None, k=None):

@@ -22,6 +22,22 @@ def bf16r(t):
     return t.to(torch.bfloat16).float()
 
 
+class bf16_storage:
+    """Context manager: inside it every oracle conv sees bf16-rounded operands and every ReLU output is rounded to bf16 --
+    the CPU emulation of what ANY bf16-storage pipeline loses on a given input (the tests' error floor)."""
+
+    def __enter__(self):
+        self._conv, self._relu = F.conv2d, F.relu
+        real_conv, real_relu = self._conv, self._relu
+        orc.F.conv2d = lambda inp, w, b=None, **k: real_conv(bf16r(inp), bf16r(w), b, **k)
+        orc.F.relu = lambda t, *a, **k: bf16r(real_relu(t))
+        return self
+
+    def __exit__(self, *exc):
+        orc.F.conv2d, orc.F.relu = self._conv, self._relu
+        return False
+
+
 def emulated(sd, x, n, has_query=True, fwd=None):
     """oracle with conv inputs/weights and every ReLU output rounded to bf16."""
     real_conv, real_relu = F.conv2d, F.relu

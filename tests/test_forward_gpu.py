@@ -8,7 +8,10 @@ which measured the reference against its OWN bf16 autocast at rel-L2 4.6e-3, arg
   logits in 'activated' mode: rel-L2 <= 2.5e-2, argmax >= 98 %.  There the fusion weights are the
       UN-renormalised P*(P>0.2) (agent.py:1060-1062), so the bf16 error of P (below) multiplies the fused
       feature map directly: dP/P ~ 1.25e-2/0.6 = 2 % measured on the 6-agent fixture.
-  prob_action: atol 2e-2.  Derivation: the policy trunk stores bf16 activations, so keys carry
+  prob_action: atol 2e-2, or 2.5x the error of the CPU bf16-storage emulation (one random draw of the same noise) on the same input where that is larger
+      (oracle/diag_forward.py::bf16_storage; per-stage attribution in profiles/r02_policy_stage_error_table.txt: rounding the
+      conv operands of ANY single stage of the policy path -- even the stem's, i.e. the input image -- already moves P by
+      1.4e-3..4.8e-3, so SURVEY 8d's guessed 2e-3 is below what a bf16 trunk can deliver).  Derivation: the policy trunk stores bf16 activations, so keys carry
       ~6e-3 relative error (measured: HIP 6.4e-3, CPU bf16-storage emulation 6.7e-3, oracle/diag_forward.py);
       delta_score ~ 6e-3*|score| with |score| up to ~8.5 on these fixtures, and |dP| <= P(1-P)*delta_score
       <= 0.25*0.07 ~ 1.7e-2.  (An fp32 score path cannot help: the error is already in the keys.)
@@ -22,6 +25,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import diag_forward as diag
 from oracle import filler
 from oracle import when2com_oracle as orc
 
@@ -91,7 +95,9 @@ def test_forward_matches_reference_vectors_and_oracle(case):
         pre = mode + "_"
         # --- communication graph
         assert prob.shape == (b, n, n) and action.shape == (b, n) and action.dtype == torch.int64
-        np.testing.assert_allclose(prob.numpy(), g[pre + "prob"], atol=P_ATOL)
+        with diag.bf16_storage():                                   # what bf16 storage alone loses on this input (CPU)
+            _, eprob, _, _ = fwd(sd, x, n, training=False, MO_flag=True, inference=mode, has_query=has_query)
+        np.testing.assert_allclose(prob.numpy(), g[pre + "prob"], atol=max(P_ATOL, 2.5 * float((eprob - rprob).abs().max())))
         top2 = rprob.topk(2, dim=1)[0]
         margin_ok = (top2[:, 0] - top2[:, 1]) > 0.04
         if mode == "softmax" or case["arch"] == "MIMOcomWho":
@@ -300,16 +306,20 @@ def test_baseline_config_shapes_match_oracle(name, arch, n, b, size, modes):
         assert pred.shape == ref.shape == (n * b, 11, size, size) and prob.shape == (b, n, n)
         p_floor = float((eprob - rprob).abs().max())
         p_err = float((prob - rprob).abs().max())
-        assert p_err <= min(max(P_ATOL, 2.5 * p_floor), 3 * P_ATOL), (mode, p_err, p_floor)
+        # P: never worse than 2x what bf16 storage alone costs on this input (who2com with query: False scores with an
+        # all-ones query -- |score| ~ 30 -- and loses 5.9e-2 in the CPU emulation already), and <= P_ATOL where that is small
+        assert p_err <= max(P_ATOL, 2.0 * p_floor), (mode, p_err, p_floor)
         # rows (q*b + sample) whose graph column is decided with margin
         top2 = rprob.topk(2, dim=1)[0]                                                   # [b, 2, n]
-        safe = ((rprob - 0.2).abs().min(dim=1)[0] >= 0.04) & ((top2[:, 0] - top2[:, 1]) >= 0.04)   # [b, n_query]
+        margin = max(0.04, 2.0 * p_floor)
+        decided = (top2[:, 0] - top2[:, 1]) >= margin                                    # [b, n_query]: argmax cannot flip
+        safe = ((rprob - 0.2).abs().min(dim=1)[0] >= margin) & decided
         if mode == "softmax":
             safe = torch.ones_like(safe)
         rows = torch.tensor([q * b + bb for q in range(n) for bb in range(b) if bool(safe[bb, q])], dtype=torch.long)
         assert len(rows) >= (n * b) // 4, "seed leaves too few margin-safe graph columns to compare"
-        assert torch.equal(action[safe], raction[safe]), mode
-        if bool(safe.all()):
+        assert torch.equal(action[decided], raction[decided]), mode
+        if mode != "softmax" and bool(safe.all()):
             assert abs(float(nconn) - float(rconn)) < 1e-9
         got, want = pred[rows].numpy(), ref[rows].numpy()
         l_err = _rel_l2(got, want)

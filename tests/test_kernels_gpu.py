@@ -264,6 +264,12 @@ def test_conv_result_is_independent_of_tile_variant_and_image_count(cin, cout, h
         part = ops.conv_igemm(x[lo:lo + n].contiguous(), 0, cin, w, cout, ks, stride, G, sc, sh,
                               residual=res[lo:lo + n].contiguous())
         assert torch.equal(part, full[lo:lo + n])
+    # ... and of how many groups are launched together (the fp8 trunk runs the policy encoder alone): group 1 of the 2-group
+    # launch == the same conv as ONE group reading its channel slice
+    solo = ops.conv_igemm(x, cin, cin, w[1:2].contiguous(), cout, ks, stride, 1, sc[cout:].contiguous(), sh[cout:].contiguous(),
+                          residual=res[..., cout:].contiguous(), ksplit=0)
+    full_k0 = ops.conv_igemm(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, ksplit=0)
+    assert torch.equal(solo, full_k0[..., cout:])
     # split-K tail layers: the split is a function of the layer, not of the image count
     full_s = ops.conv_igemm(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, ksplit=0)
     for lo, n in ((0, 1), (7, 4)):

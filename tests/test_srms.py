@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import filler
+from oracle import diag_forward as diag
 from oracle import when2com_oracle as orc
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -113,9 +114,13 @@ def test_hip_forward_matches_reference_vectors_and_oracle(case):
         pred, prob, action = res[0].cpu(), res[1].cpu(), res[2].cpu()
         pre = mode + "_"
         assert prob.shape == (b, 1, nk) and pred.shape == (b, 11, s, s) and pred.dtype == torch.float32
-        np.testing.assert_allclose(prob.numpy(), g[pre + "prob"], atol=2e-2)
+        # P within 2e-2, or 2.5x what bf16 storage alone loses on this input (CPU emulation) where that is larger
+        with diag.bf16_storage():
+            eref = fwd(sd, x, training=False, inference=mode, **kw)
+        p_tol = max(2e-2, 2.5 * float((eref[1] - ref[1]).abs().max()))
+        np.testing.assert_allclose(prob.numpy(), g[pre + "prob"], atol=p_tol)
         if mode == "activated":                                     # returns W * (W > 0.2); fixtures keep 0.04 from the threshold
-            np.testing.assert_allclose(action.numpy(), g[pre + "action"], atol=2e-2)
+            np.testing.assert_allclose(action.numpy(), g[pre + "action"], atol=p_tol)
         else:
             assert action.dtype == torch.int64
             np.testing.assert_array_equal(action.numpy(), g[pre + "action"])
