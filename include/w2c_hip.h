@@ -146,6 +146,22 @@ int w2c_conv_igemm_fp8(const void* x, int x_is_fp8, int M, int H, int W, int Cin
                        uint16_t* y_bf16, int y_cstride, long long y_group_stride,
                        uint8_t* y_fp8, int y8_cstride, float y8_scale,
                        const void* zero_page, int variant, w2c_stream_t stream);
+/* ---- the front of a stride-2 BasicBlock in ONE launch: t = relu(bn1(conv1 3x3/s2/p1 (x))) and
+ * idt = downsample.1(downsample.0 1x1/s2 (x)) (third-party resnet18 BasicBlock, backbone.py:66-69).  The 3x3 conv's
+ * centre tap reads exactly the 1x1 conv's pixels (input (2oy, 2ox)), so the staged pixel tile is multiplied with a second
+ * weight tile at the centre-tap K-steps: one pass over x and one launch less per block; per output the MFMA sequence is
+ * that of the separate w2c_conv_igemm_* calls (bit-identical results).
+ * x : bf16 or e4m3 (x_is_fp8) NHWC; w3 [groups][Cout][9][Cin], w1 [groups][Cout][Cin] in x's operand type;
+ * t : bf16 (t_bf16, nullable) and/or e4m3(t / t8_scale) (t_fp8, nullable), ReLU applied;  idt : bf16, no ReLU.
+ * Groups side by side in every output.  variant < 0: library's choice (0 / 3 / 6 = 128x128 / 128x64 / 64x64 tiles). */
+int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int W, int Cin, int x_cstride,
+                      const void* w3, const float* scale3, const float* shift3,
+                      const void* w1, const float* scale1, const float* shift1,
+                      int Cout, int groups,
+                      uint16_t* t_bf16, int t_cstride, uint8_t* t_fp8, int t8_cstride, float t8_scale,
+                      uint16_t* idt_bf16, int idt_cstride,
+                      const void* zero_page, int variant, w2c_stream_t stream);
+
 /* Unit-test probes of the two fp8 primitives: c[32][32] f32 = a[32][64] . b[32][64]^T (e4m3, one MX-scaled MFMA with
  * unit block scales); y[n] = e4m3(x[n]) as the conv epilogues pack it (round to nearest even, saturating). */
 int w2c_debug_mx_mfma(const uint8_t* a, const uint8_t* b, float* c, w2c_stream_t stream);

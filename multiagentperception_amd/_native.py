@@ -34,6 +34,8 @@ SIGNATURES = {
     "w2c_debug_conv_timeline": [_vp],
     "w2c_conv_igemm_fp8": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _vp, _i, _f,
                            _vp, _i, _vp],
+    "w2c_conv_s2_block": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i,
+                          _vp, _i, _vp],
     "w2c_debug_mx_mfma": [_vp, _vp, _vp, _vp],
     "w2c_debug_fp8_pack": [_vp, _vp, _i, _vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],

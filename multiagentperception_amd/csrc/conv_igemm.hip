@@ -56,6 +56,12 @@ struct ConvArgs {
     uint8_t* y8;               // optional second output: fp8 e4m3 copy of the result (groups side by side), value * q8
     int y8cs;
     float q8;
+    // DUAL kernels (a stride-2 BasicBlock's conv1 + its 1x1/s2 downsample from one staged input): the 1x1 conv's operands
+    const uint16_t* w2;        // [groups][Cout][Cin], operand type of w
+    const float* scale2;
+    const float* shift2;
+    uint16_t* y2;              // bf16, groups side by side, pixel stride y2cs; no ReLU, no residual
+    int y2cs;
 };
 
 // element size / channels per K-step of the two operand types: a K-step is always ONE 128-byte run per row
@@ -108,7 +114,11 @@ __device__ __forceinline__ void pipeline_barrier() {
 // tiles go to p.ws as f32 and splitk_finish_kernel sums them in split order (fixed order: deterministic) and runs
 // the epilogue.  For the tail layers (<= 80 tiles under a long, weight-streaming K loop) this turns a 36-step
 // latency chain into 4-5 steps on 8x the CUs.
-template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool SPLITK = false, bool F8 = false>
+// DUAL: a 3x3 / stride-2 / pad-1 conv whose centre tap reads exactly the pixels of the block's 1x1 / stride-2 downsample
+// (input (2oy, 2ox)): at the centre-tap K-steps the staged pixel tile is multiplied with a second weight tile into a
+// second accumulator set, and the epilogue runs twice.  Same MFMA sequence per output as the two separate launches
+// (bit-identical), one launch and one pass over the input less per stride-2 block.
+template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool SPLITK = false, bool F8 = false, bool DUAL = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -128,8 +138,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     static_assert(BK == 64, "BK: one K-step = one 64-channel chunk of one tap (the K order every kernel shares)");
     static_assert(A_INSTR >= 1 && B_INSTR >= 1 && A_INSTR * RPI * NW == BM && B_INSTR * RPI * NW == BN, "DMA split");
     static_assert(STAGES >= 2 && (STAGES - 2) * LOADS < 64, "vmcnt range");
+    static_assert(!DUAL || (STAGES == 2 && !SPLITK), "DUAL: the extra tile's DMAs rely on the 2-stage ring's full vmcnt drain");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const B2s = smem + STAGES * STAGE_BYTES;     // DUAL: the downsample's weight tile (single buffer, used once per chunk)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,6 +166,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(wg), 0, (int)((size_t)p.Cout * Ktot * ES), 0x00020000);
+    const char* wg2 = DUAL ? reinterpret_cast<const char*>(p.w2) + (size_t)g * p.Cout * p.Cin * ES : wg;
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wg2), 0, (int)((size_t)p.Cout * p.Cin * ES), 0x00020000);
     const int lrow = lane / LPR;           // row within a DMA group
     const int lpos = lane % LPR;           // 16-B position within the LDS row
     auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
@@ -181,6 +196,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     for (int j = 0; j < B_INSTR; ++j) {
         const int n = (wave + NW * j) * RPI + lrow;
         b_off[j] = (unsigned)((size_t)(n0 + n) * Ktot * ES + (lpos ^ swz(n)) * 16);
+    }
+    unsigned b2_off[B_INSTR];
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+        const int n = (wave + NW * j) * RPI + lrow;
+        b2_off[j] = (unsigned)((size_t)(n0 + n) * p.Cin * ES + (lpos ^ swz(n)) * 16);
     }
 
     // K-step range of this workgroup and cursor (wave-uniform): tap (ky,kx) and channel chunk
@@ -211,6 +232,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         for (int j = 0; j < B_INSTR; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(Bs + (wave + NW * j) * 1024), 16, b_off[j],
                                                      (st_ky * p.ks + st_kx) * p.Cin * ES + st_ct * BK * 2, 0, 0);
+        if constexpr (DUAL) {
+            if (st_ky == 1 && st_kx == 1) {              // centre tap: the 1x1 conv's weight tile of this channel chunk
+#pragma unroll
+                for (int j = 0; j < B_INSTR; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, W2C_LPTR(B2s + (wave + NW * j) * 1024), 16, b2_off[j],
+                                                             st_ct * BK * 2, 0, 0);
+            }
+        }
         if (++st_kx == p.ks) {
             st_kx = 0;
             if (++st_ky == p.ks) { st_ky = 0; ++st_ct; }
@@ -225,6 +254,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    f32x16_t acc2[DUAL ? MI : 1][DUAL ? NI : 1];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+    }
+
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int lswz = swz(l31);             // tile / wave offsets are multiples of 32: swz(row) == swz(l31)
@@ -235,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssp), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssp + 4);
     const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, bool centre) {
         const char* As = smem + buf * STAGE_BYTES;
         const char* Bs = As + A_BYTES;
         if constexpr (F8) {
@@ -270,6 +309,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
             for (int i = 0; i < MI; ++i)             // keep the MFMAs of this K-step in this K-step (see the patch kernel)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc[i][j]));
+            if constexpr (DUAL) {
+                if (centre) {                         // wave-uniform
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int p0 = ((j2 * 4 + lhi * 2) ^ lswz) << 4, p1 = ((j2 * 4 + lhi * 2 + 1) ^ lswz) << 4;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const char* r = B2s + (wn * WTN + j * 32 + l31) * ROWB;
+                            const i32x8_t w8 = cat_i32x8(*reinterpret_cast<const u32x4_t*>(r + p0), *reinterpret_cast<const u32x4_t*>(r + p1));
+#pragma unroll
+                            for (int i = 0; i < MI; ++i)
+                                acc2[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8[j2][i], acc2[i][j], 0, 0, 0,
+                                                                                             0x7F7F7F7F, 0, 0x7F7F7F7F);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc2[i][j]));
+                }
+            }
             return;
         }
         bf16x8_t a[KSUB][MI], b[KSUB][NI];
@@ -291,6 +351,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
                 for (int j = 0; j < NI; ++j)
                     // A = weights, B = pixels: D[channel][pixel] -- four consecutive channels of a pixel per accumulator quad
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
+        if constexpr (DUAL) {
+            if (centre) {                             // wave-uniform: the downsample's products, same pixel fragments
+#pragma unroll
+                for (int kk = 0; kk < KSUB; ++kk) {
+                    const int pos = ((kk * 2 + lhi) ^ lswz) << 4;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const bf16x8_t w2f = *reinterpret_cast<const bf16x8_t*>(B2s + (wn * WTN + j * 32 + l31) * ROWB + pos);
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f, a[kk][i], acc2[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
     };
 
     // ---- main loop: STAGES-deep ring, counted waits, one barrier per K-step ----
@@ -300,13 +375,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         if (s < KT) stage(s);
     int rd = 0;                      // buffer holding tile t
     int wr = STAGES - 1;             // buffer the next DMA goes to (== buffer of tile t-1)
+    int c_tap = 0;                   // DUAL: tap index (0..8) of the tile being computed (t_begin = 0 there)
     for (int t = 0; t < KT; ++t) {
         if (t + STAGES - 2 < KT) wait_vmcnt<(STAGES - 2) * LOADS>();     // tile t (my part) has landed
         else wait_vmcnt<0>();
         pipeline_barrier();                                              // everyone's part landed; tile t-1's buffer is free
         if (t == 0) dbg_stamp(p, 1);
         if (t + STAGES - 1 < KT) stage(wr);
-        compute(rd);
+        compute(rd, DUAL && c_tap == 4);
+        if (DUAL) c_tap = (c_tap == 8) ? 0 : c_tap + 1;
         rd = (rd + 1 == STAGES) ? 0 : rd + 1;
         wr = (wr + 1 == STAGES) ? 0 : wr + 1;
     }
@@ -389,6 +466,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         }
         if (e_ok[ps]) store_out8(p, v, e_off[ps], e_off8[ps]);
     }
+    if constexpr (DUAL) {
+        // ---- second output: the 1x1/s2 downsample (BN folded, no ReLU, no residual), bf16, groups side by side ----
+        __syncthreads();                                  // every thread is done reading the first tile out of Cs
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * WTM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg)
+                    *reinterpret_cast<f32x4_t*>(Cs + ml * CLD + wn * WTN + j * 32 + eg * 8 + lhi * 4) =
+                        f32x4_t{acc2[i][j][eg * 4], acc2[i][j][eg * 4 + 1], acc2[i][j][eg * 4 + 2], acc2[i][j][eg * 4 + 3]};
+        }
+        __syncthreads();
+        const float* ssp2 = p.scale2 + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+        const float* shp2 = p.shift2 + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+        const f32x4_t sc0 = *reinterpret_cast<const f32x4_t*>(ssp2), sc1 = *reinterpret_cast<const f32x4_t*>(ssp2 + 4);
+        const f32x4_t sh0 = *reinterpret_cast<const f32x4_t*>(shp2), sh1 = *reinterpret_cast<const f32x4_t*>(shp2 + 4);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int idx = ps * NT + tid;
+            const int r = idx / CG, cg = idx - r * CG;
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8) * sc0 + sh0;
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4) * sc1 + sh1;
+            if (e_ok[ps]) {
+                uint4 o;
+                o.x = pack_bf16x2(v0[0], v0[1]); o.y = pack_bf16x2(v0[2], v0[3]);
+                o.z = pack_bf16x2(v1[0], v1[1]); o.w = pack_bf16x2(v1[2], v1[3]);
+                *reinterpret_cast<uint4*>(p.y2 + (size_t)(m0 + r) * p.y2cs + (size_t)g * p.Cout + n0 + cg * 8) = o;
+            }
+        }
+    }
     dbg_stamp(p, 3);
 #endif
 }
@@ -406,7 +515,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 // one barrier per tap, counted vmcnt, patch double-buffered across channel chunks.
 // LDS patch image: one 128-B row per patch pixel, 16-B chunk c of pixel q at c ^ ((q>>1)&7) -- the
 // ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
-template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB, bool F8 = false>
+// PIPE: the fragment reads of K-step t+1 are issued BEFORE the MFMAs of K-step t (two register sets), so the LDS round trip
+// of a step runs under the previous step's matrix work instead of in front of its own; the barrier at the top of iteration t
+// then certifies tile t+1, and the weight ring holds STAGES tiles in flight instead of STAGES-1 in the same LDS.
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB, bool F8 = false, bool PIPE = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;  // operand bytes per element / channels per 128-byte K-step
@@ -531,14 +643,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssp), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssp + 4);
     const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
 
-    bf16x8_t fa[F8 ? 1 : 4][MI], fb[F8 ? 1 : 4][NI];            // fragment registers of ONE K-step (tap)
-    i32x8_t fa8[F8 ? 2 : 1][MI], fb8[F8 ? 2 : 1][NI];           // fp8 form: two K=64 MFMAs per 128-byte row
+    struct Frags {
+        bf16x8_t fa[F8 ? 1 : 4][MI], fb[F8 ? 1 : 4][NI];       // fragment registers of ONE K-step (tap)
+        i32x8_t fa8[F8 ? 2 : 1][MI], fb8[F8 ? 2 : 1][NI];      // fp8 form: two K=64 MFMAs per 128-byte row
+    };
+    Frags fr0, fr1;                                             // fr1 only lives in the PIPE form
     // LDS slot of chunk c of patch pixel (row, col): c ^ ((col >> 1) & 7), at byte (row*PW + col)*128.  Keyed on the COLUMN:
     // a wave's 32 pixels lie on two patch rows when TW = 16, and ds_read_b128 services lanes {0-3,12-15,20-27} (etc.)
     // together -- columns {c..c+3, c+12..c+15} of one row and {c+4..c+11} of the next, a complete residue system mod 16 =>
     // 16 distinct 16-B slots of the 256-B bank row.  (Keyed on the linear pixel index the two rows collide: PMC showed
     // 33 % of the LDS cycles of these kernels were bank conflicts.)
-    auto load_frags = [&](const char* patch, const char* Bs, int dk, int kx) {
+    auto load_frags = [&](Frags& fr, const char* patch, const char* Bs, int dk, int kx) {
+        auto& fa = fr.fa; auto& fb = fr.fb; auto& fa8 = fr.fa8; auto& fb8 = fr.fb8;
         const char* arow[MI];
         int aswz[MI];
 #pragma unroll
@@ -575,7 +691,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
                                                                (((kk * 2 + lhi) ^ bswz) << 4));
         }
     };
-    auto mfma_all = [&]() {
+    auto mfma_all = [&](Frags& fr) {
+        auto& fa = fr.fa; auto& fb = fr.fb; auto& fa8 = fr.fa8; auto& fb8 = fr.fb8;
         if constexpr (F8) {
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2)
@@ -613,6 +730,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #ifdef W2C_PHASE_TIMING
     long long ph[5] = {0, 0, 0, 0, 0};
 #endif
+    if constexpr (PIPE) {
+        // ring of STAGES slots, tile t in slot t % STAGES; iteration t: [tile t+1 landed] barrier -> DMA tile t+STAGES into
+        // the slot tile t was read from (its reads were drained by the barrier's lgkmcnt(0)) -> read tile t+1's fragments
+        // -> MFMAs of tile t from the registers read one iteration earlier.
+        issue_patch(0, 0);
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) issue_b(s);           // KT >= 9 > STAGES
+        wait_vmcnt<(STAGES - 1) * B_INSTR>();                   // patch(0) and tile 0 (older than tiles 1..STAGES-1)
+        pipeline_barrier();
+        dbg_stamp(p, 1);
+        load_frags(fr0, patch0, bring, 0, 0);
+        int nx = (1 == STAGES) ? 0 : 1;                         // slot of tile t+1
+        int wr = 0;                                             // slot of tile t (= where tile t+STAGES goes)
+        int t = 0;
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const char* patch = patch0 + (PB == 2 ? (cc & 1) : 0) * PATCH_BYTES;
+            const char* patch_n = patch0 + (PB == 2 ? ((cc + 1) & 1) : 0) * PATCH_BYTES;
+            const bool more = cc + 1 < nchunks;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap, ++t) {
+                // tile t+1 (and, when it opens chunk cc+1, patch(cc+1): older than that tile) must have landed.  Younger
+                // loads allowed in flight: tiles t+2..t+STAGES-1, plus patch(cc+1) while it is younger than tile t+1
+                // (issued at tap 0 right after tile t0+STAGES).
+                if (t + 1 < KT) {
+                    if (t + STAGES - 1 < KT) {
+                        if (more && tap >= 1 && tap <= STAGES - 1) wait_tiles_and_patch(KS2{});
+                        else wait_vmcnt<(STAGES - 2) * B_INSTR>();
+                    } else {
+                        wait_vmcnt<0>();
+                    }
+                }
+                pipeline_barrier();
+                if (t + STAGES < KT) issue_b(wr);
+                if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
+                if (t + 1 < KT) {
+                    if (tap < 8) load_frags(fr1, patch, bring + nx * B_BYTES, ((tap + 1) / 3) * PW + ((tap + 1) % 3), (tap + 1) % 3);
+                    else load_frags(fr1, patch_n, bring + nx * B_BYTES, 0, 0);
+                }
+                mfma_all(fr0);
+                fr0 = fr1;                                      // renamed away inside the unrolled taps; a move per chunk
+                nx = (nx + 1 == STAGES) ? 0 : nx + 1;
+                wr = (wr + 1 == STAGES) ? 0 : wr + 1;
+            }
+        }
+        __syncthreads();
+        dbg_stamp(p, 2);
+    } else {
     issue_patch(0, 0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
@@ -643,7 +807,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #endif
             if (t == 0) dbg_stamp(p, 1);
 #ifdef W2C_READS_FIRST     // measured: fragment reads ahead of the DMA issue is SLOWER (l2 v30 55 -> 66 us at equal clocks)
-            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3), tap % 3);
+            load_frags(fr0, patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3), tap % 3);
 #endif
             if (t + STAGES - 1 < KT) issue_b(wr);
             if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
@@ -651,13 +815,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
             const long long c3 = clock64();
 #endif
 #ifndef W2C_READS_FIRST
-            load_frags(patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3), tap % 3);
+            load_frags(fr0, patch, bring + rd * B_BYTES, (tap / 3) * PW + (tap % 3), tap % 3);
 #endif
 #ifdef W2C_PHASE_TIMING
             asm volatile("" ::: "memory");
             const long long c4 = clock64();
 #endif
-            mfma_all();
+            mfma_all(fr0);
 #ifdef W2C_PHASE_TIMING
             const long long c5 = clock64();
             ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
@@ -668,6 +832,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     }
     __syncthreads();     // fenced: the epilogue's staging stores must not be hoisted above this barrier
     dbg_stamp(p, 2);
+    }
 #ifdef W2C_PHASE_TIMING
     if (p.dbg && (threadIdx.x & 63) == 0) {          // lane 0 of every wave: [WG][wave][5] after the 4 stamps region
         unsigned long long* o = p.dbg + (1u << 19) + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 5;
@@ -1069,7 +1234,7 @@ int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
 }
 
 
-template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2, bool F8 = false>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2, bool F8 = false, bool PIPE = false>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int CK = OpT<F8>::CK;
     if (a.ks != 3 || a.stride != 1 || a.Cin % CK != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
@@ -1085,12 +1250,12 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8, PIPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8, PIPE>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -1202,28 +1367,44 @@ SplitPlan plan_splitk(const ConvArgs& a, int groups, int want) {
     return sp;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool F8 = false>
+template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool F8 = false, bool DUAL = false>
 int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int CK = OpT<F8>::CK;
     if (a.Cin % CK != 0 || a.Cout % BN != 0) return W2C_E_ARG;
+    if (DUAL && (a.ks != 3 || a.stride != 2 || !a.w2 || !a.y2)) return W2C_E_ARG;
     a.cin_tiles = a.Cin / CK;
     a.ktiles = a.ks * a.ks * a.cin_tiles;
     a.ntm = (a.rows + BM - 1) / BM;
     a.ntn = a.Cout / BN;
-    constexpr int lds = conv_lds_bytes<BM, BN, BK, STAGES>();
+    constexpr int ring = STAGES * (BM + BN) * BK * 2 + (DUAL ? BN * BK * 2 : 0);      // DUAL: + the 1x1 conv's weight tile
+    constexpr int lds = ring > conv_lds_bytes<BM, BN, BK, STAGES>() ? ring : conv_lds_bytes<BM, BN, BK, STAGES>();
     static_assert(lds <= 160 * 1024, "LDS");
     // dynamic LDS above 64 KiB needs the attribute once per device; keep a per-device bit.
     static unsigned long long attr_mask = 0;   // benign race: every thread writes the same attribute
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8, DUAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8, DUAL>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
+}
+
+// stride-2 BasicBlock front (conv1 3x3/s2 + downsample 1x1/s2) in one launch; tile chosen like pick_variant's generic rules
+template <bool F8>
+int launch_dual(ConvArgs& a, int groups, int variant, hipStream_t s) {
+    const long rows = a.rows;
+    (void)rows;
+    if (variant < 0) variant = 6;       // two accumulator sets: 64x64 tiles keep 2 waves per SIMD (128x128: 288 registers, 1 wave)
+    switch (variant) {
+        case 0: return launch_conv<128, 128, 2, 2, 64, 2, F8, true>(a, groups, s);
+        case 3: return launch_conv<128, 64, 2, 2, 64, 2, F8, true>(a, groups, s);
+        case 6: return launch_conv<64, 64, 2, 2, 64, 2, F8, true>(a, groups, s);
+        default: return W2C_E_ARG;
+    }
 }
 
 // Variant table (index = `variant` of w2c_conv_igemm_bf16_variant; tools/bench_conv.py sweeps it).  Only the variants
@@ -1245,6 +1426,10 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
+        // PIPE forms of 30 / 36 / 38: next step's fragment reads under this step's MFMAs
+        case 130: return launch_patch<8, 16, 128, 2, 2, 2, 2, false, true>(a, groups, s);
+        case 136: return launch_patch<8, 16, 64, 4, 2, 3, 2, false, true>(a, groups, s);
+        case 138: return launch_patch<8, 16, 64, 2, 2, 2, 1, false, true>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -1260,6 +1445,10 @@ int launch_variant_f8(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 36: return launch_patch<8, 16, 64, 4, 2, 3, 2, true>(a, groups, s);
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1, true>(a, groups, s);      // Cin == 128: one chunk
         case 40: return launch_patch<8, 16, 128, 2, 2, 2, 1, true>(a, groups, s);     // Cin == 128, 128 channels per tile
+        case 130: return launch_patch<8, 16, 128, 2, 2, 2, 2, true, true>(a, groups, s);
+        case 136: return launch_patch<8, 16, 64, 4, 2, 3, 2, true, true>(a, groups, s);
+        case 138: return launch_patch<8, 16, 64, 2, 2, 2, 1, true, true>(a, groups, s);
+        case 140: return launch_patch<8, 16, 128, 2, 2, 2, 1, true, true>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -1301,6 +1490,9 @@ int pick_variant(const ConvArgs& a, int groups) {
         if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
         if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;
     }
+    // stride-2 3x3: the 128x64 tile beats 128x128 at every cfg-2 shape (tools/bench_s2_block.py: 46.1 / 36.9 / 36.5 us vs
+    // 47.7 / 42.8 / 38.1 us) -- twice the workgroups for a kernel whose K-step is dominated by the 9x re-gather of its rows
+    if (a.stride == 2 && a.ks == 3 && Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
     if (Cout % 128 == 0 && (rows / 128) * (Cout / 128) * groups >= 512) return 0;
     if (Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
     if (Cout % 64 == 0) return 6;
@@ -1341,6 +1533,7 @@ int fill_args(ConvArgs& a, const void* x, int M, int H, int W, int Cin, int x_cs
     a.n_split = 1;
     a.ygs = y_group_stride;
     a.y8 = y8; a.y8cs = y8_cstride; a.q8 = y8 ? 1.f / y8_scale : 1.f;
+    a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.y2 = nullptr; a.y2cs = 0;
     return W2C_OK;
 }
 
@@ -1437,6 +1630,24 @@ extern "C" int w2c_conv_igemm_fp8(const void* x, int x_is_fp8, int M, int H, int
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (x_is_fp8) return launch_variant_f8(variant >= 0 ? variant : pick_variant_f8(a, groups), a, groups, s);
     return launch_variant(variant >= 0 ? variant : pick_variant(a, groups), a, groups, s);
+}
+
+extern "C" int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int W, int Cin, int x_cstride,
+                                 const void* w3, const float* scale3, const float* shift3,
+                                 const void* w1, const float* scale1, const float* shift1,
+                                 int Cout, int groups,
+                                 uint16_t* t_bf16, int t_cstride, uint8_t* t_fp8, int t8_cstride, float t8_scale,
+                                 uint16_t* idt_bf16, int idt_cstride,
+                                 const void* zero_page, int variant, w2c_stream_t stream) {
+    w2c_clear_error();
+    ConvArgs a;
+    int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w3, Cout, 3, 2, groups, scale3, shift3, nullptr, 1,
+                       t_bf16, t_cstride, 0, zero_page, 0, x_is_fp8 != 0, t_fp8, t8_cstride, t8_scale);
+    if (rc != W2C_OK) return rc;
+    if (!w1 || !scale1 || !shift1 || !idt_bf16 || idt_cstride < groups * Cout || (idt_cstride % 8) != 0) return W2C_E_ARG;
+    a.w2 = reinterpret_cast<const uint16_t*>(w1); a.scale2 = scale1; a.shift2 = shift1; a.y2 = idt_bf16; a.y2cs = idt_cstride;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return x_is_fp8 ? launch_dual<true>(a, groups, variant, s) : launch_dual<false>(a, groups, variant, s);
 }
 
 // One wave: C[32][32] (f32, row-major) = A[32][64] * B[32][64]^T with e4m3 operands through the MX-scaled MFMA with unit

@@ -120,6 +120,29 @@ class Fp8ConvPlan:
                             out_groups=out_groups, out=out, out_ch_off=out_ch_off)
 
 
+def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
+    """conv1 (+ the 1x1/s2 downsample of a stride-2 block) of a BasicBlock on x -> (t, identity).  Stride-2 blocks run
+    both convs as ONE launch (w2c_conv_s2_block: the 3x3's centre tap IS the 1x1's input); W2C_NO_DUAL=1 keeps the two
+    separate launches (bit-identical, for A/B timing).  With t_fp8_scale, t is the fp8 tensor (Fp8ConvPlans)."""
+    f8 = t_fp8_scale is not None
+    if ds is None:
+        if f8:
+            return c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1], None
+        return c1.run(x, x_ch_off=x_ch_off), x
+    # one launch pays on the larger maps only (tools/bench_s2_block.py, cfg 2: layer2.0 61.7 vs 67.9 us, layer3.0 52.0 vs
+    # 57.3 us, layer4.0 55.1 vs 48.0 us): below ~16 k output pixels the two kernels' smaller register footprint wins.
+    # Either way the bits are the same.
+    Ho, Wo = (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2
+    if os.environ.get("W2C_NO_DUAL") or x.shape[0] * Ho * Wo < 16384:
+        if f8:
+            return (c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1],
+                    ds.run(x, x_ch_off=x_ch_off)[0])
+        return c1.run(x, x_ch_off=x_ch_off), ds.run(x, x_ch_off=x_ch_off)
+    t16, t8, idt = ops.conv_s2_block(x, x_ch_off, c1.cin, c1.w, c1.scale, c1.shift, ds.w, ds.scale, ds.shift, c1.cout,
+                                     c1.groups, t_bf16=not f8, t_fp8_scale=t_fp8_scale)
+    return (t8 if f8 else t16), idt
+
+
 class TrunkPlan:
     """G ResNet-18 trunks + squeezers run side by side (G = 1 for Single_agent, 2 for MIMOcom*).
 
@@ -185,9 +208,11 @@ class TrunkPlan:
             if self.fp8 is None:
                 self.calibrate(p)
             return self._after_stem_fp8(p, squeezer_out)
+        # (Measured and rejected, profiles/r02_concurrency_experiments.txt: the 1x1/s2 downsample on a side stream beside
+        # conv1 (-1 %), and the batch cut into 2-3 slices on parallel streams to fill the workgroup-quantisation tails
+        # (-9..-15 %): full-size bf16 launches leave no room for a second kernel.)
         for c1, c2, ds in self.blocks:
-            t = c1.run(p)
-            idt = p if ds is None else ds.run(p)
+            t, idt = _block_front(c1, ds, p)
             p = c2.run(t, residual=idt)
         return self.squeezer.run(p, out_groups=squeezer_out)
 
@@ -201,8 +226,7 @@ class TrunkPlan:
         amax = []
         q = p
         for bi, (c1, c2, ds) in enumerate(self.blocks):
-            t = c1.run(q)
-            idt = q if ds is None else ds.run(q)
+            t, idt = _block_front(c1, ds, q)
             q = c2.run(t, residual=idt)
             if bi >= 2:
                 c = t.shape[3] // G * n8                                         # channels of the fp8 trunks (they come first)
@@ -261,9 +285,8 @@ class TrunkPlan:
         nb = len(self.fp8["blocks"])
         for i, (c1, c2, ds, t_step, o_step) in enumerate(self.fp8["blocks"]):
             src = x16 if x8 is None else x8                                      # layer2.0 reads layer1's bf16 output
-            _, t8 = c1.run(src, out_bf16=False, out_fp8_scale=t_step)
-            idt = x16 if ds is None else ds.run(src)[0]
-            x16, x8 = c2.run(t8, residual=idt, out_bf16=(i + 1 < nb), out_fp8_scale=o_step)
+            t8, idt = _block_front(c1, ds, src, t_fp8_scale=t_step)
+            x16, x8 = c2.run(t8, residual=x16 if ds is None else idt, out_bf16=(i + 1 < nb), out_fp8_scale=o_step)
         if squeezer_out is not None:
             self.fp8["squeezer"].run(x8, out_groups=squeezer_out[:n8])
         else:
@@ -286,8 +309,7 @@ class TrunkPlan:
         n8 = self.n8
         q, off = p, 64 * n8
         for c1, c2, ds in self.fp8["rest"]:
-            t = c1.run(q, x_ch_off=off)
-            idt = ds.run(q, x_ch_off=off) if ds is not None else q
+            t, idt = _block_front(c1, ds, q, x_ch_off=off)
             q, off = c2.run(t, residual=idt), 0
         if squeezer_out is not None:
             self.fp8["rest_squeezer"].run(q, out_groups=squeezer_out[n8:])
@@ -486,7 +508,7 @@ class CommEngine:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             low, prob, action, nnz = middle(s0)
         return s0, graph, low, prob, action, nnz
 

@@ -338,6 +338,45 @@ def conv_fp8(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shi
     return (list(out_groups) if out_groups is not None else y), y8
 
 
+def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout, groups, t_bf16=True, t_fp8_scale=None,
+                  variant=-1):
+    """Front of a stride-2 BasicBlock in one launch (include/w2c_hip.h w2c_conv_s2_block): returns (t bf16 | None,
+    t fp8 (uint8) | None, idt bf16).  x bf16 or uint8 (e4m3) NHWC; w3 [G,Cout,9*cin], w1 [G,Cout,cin] in x's operand type."""
+    dev = _need_gpu(x, w3, scale3, shift3, w1, scale1, shift1)
+    f8 = x.dtype == torch.uint8
+    want = torch.uint8 if f8 else BF16
+    if (not f8 and x.dtype != BF16) or w3.dtype != want or w1.dtype != want:
+        raise W2CError("conv_s2_block: x / w3 / w1 must share one operand type (bf16 or uint8 e4m3)")
+    M, H, W, xcs = x.shape
+    if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
+        raise W2CError("conv_s2_block: channels outside the tensor")
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    t16 = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev) if t_bf16 else None
+    t8 = torch.empty((M, Ho, Wo, groups * cout), dtype=torch.uint8, device=dev) if t_fp8_scale is not None else None
+    if t16 is None and t8 is None:
+        raise W2CError("conv_s2_block: no conv1 output requested")
+    idt = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    es = 1 if f8 else 2
+    timer = getattr(_tls, "conv_timer", None)
+    if timer is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_s2_block(x.data_ptr() + es * x_ch_off, 1 if f8 else 0, M, H, W, cin, xcs, _p(w3), _p(scale3),
+                                              _p(shift3), _p(w1), _p(scale1), _p(shift1), cout, groups, _p(t16), groups * cout,
+                                              _p(t8), groups * cout, float(t_fp8_scale) if t_fp8_scale is not None else 1.0,
+                                              _p(idt), groups * cout, _p(zero_page(dev)), int(variant), _stream(dev)),
+              "w2c_conv_s2_block")
+    if timer is not None:
+        ev1.record(torch.cuda.current_stream(dev))
+        flops = 2.0 * M * Ho * Wo * cout * (10 * cin) * groups
+        nbytes = (M * H * W * cin * groups * es + M * Ho * Wo * cout * groups * ((2 if t16 is not None else 0) + (1 if t8 is not None else 0) + 2)
+                  + groups * cout * 10 * cin * es)
+        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, "3+1", 2, groups), nbytes))
+    return t16, t8, idt
+
+
 def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
     """y[M,O] = act(x[M,K] W^T + b); x bf16 or f32 (2-D view given by rows/k/x_stride)."""
     dev = _need_gpu(x, w, b)

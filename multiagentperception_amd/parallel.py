@@ -149,7 +149,7 @@ class _ShardState:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 res = fn()
             self.graphs[name] = (g, res)
             g = self.graphs[name]

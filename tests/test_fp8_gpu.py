@@ -143,7 +143,7 @@ def test_conv_fp8_result_is_independent_of_variant_and_image_count(cin, cout, hw
     res = torch.randn(M, ho, ho, G * cout, generator=gen).to(BF16).to(_dev())
     f16, f8 = ops.conv_fp8(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, out_fp8_scale=0.05)
     tried = 0
-    for v in (0, 3, 6, 36, 38, 40):
+    for v in (0, 3, 6, 36, 38, 40, 130, 136, 138, 140):
         try:
             a16, a8 = ops.conv_fp8(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, out_fp8_scale=0.05, variant=v)
         except W2CError:
@@ -155,6 +155,22 @@ def test_conv_fp8_result_is_independent_of_variant_and_image_count(cin, cout, hw
         p16, p8 = ops.conv_fp8(x[lo:lo + n].contiguous(), 0, cin, w, cout, ks, stride, G, sc, sh,
                                residual=res[lo:lo + n].contiguous(), out_fp8_scale=0.05)
         assert torch.equal(p16, f16[lo:lo + n]) and torch.equal(p8, f8[lo:lo + n])
+
+
+@pytest.mark.parametrize("cin,cout,hw,M,G", [(128, 256, 32, 6, 2), (256, 512, 16, 20, 1), (128, 128, 17, 2, 1)])
+def test_fp8_stride2_block_front_in_one_launch_equals_the_two_convs(cin, cout, hw, M, G):
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(cin + cout + hw)
+    x = torch.randn(M, hw, hw, G * cin, generator=gen).mul(4).to(FP8).view(torch.uint8).to(_dev())
+    w3 = torch.randn(G, cout, 9 * cin, generator=gen).mul(50).clamp(-448, 448).to(FP8).view(torch.uint8).to(_dev())
+    w1 = torch.randn(G, cout, cin, generator=gen).mul(50).clamp(-448, 448).to(FP8).view(torch.uint8).to(_dev())
+    sc3, sc1 = [((torch.rand(G * cout, generator=gen) + 0.5) * 1e-4).to(_dev()) for _ in range(2)]
+    sh3, sh1 = [(torch.randn(G * cout, generator=gen) * 0.1).to(_dev()) for _ in range(2)]
+    _, t8_ref = ops.conv_fp8(x, 0, cin, w3, cout, 3, 2, G, sc3, sh3, relu=True, out_bf16=False, out_fp8_scale=0.02)
+    i_ref, _ = ops.conv_fp8(x, 0, cin, w1, cout, 1, 2, G, sc1, sh1, relu=False)
+    for v in (-1, 0, 3, 6):
+        t, t8, idt = ops.conv_s2_block(x, 0, cin, w3, sc3, sh3, w1, sc1, sh1, cout, G, t_bf16=False, t_fp8_scale=0.02, variant=v)
+        assert t is None and torch.equal(t8, t8_ref) and torch.equal(idt, i_ref), "variant %d" % v
 
 
 def _cfg(arch, n, size, query):

@@ -211,7 +211,8 @@ def test_conv_splitk_matches_fp32_and_is_deterministic(case):
 
 
 @pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128),
-                                                 (36, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16)])
+                                                 (36, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16),
+                                                 (130, 128, 128, 64), (136, 256, 256, 32), (136, 512, 512, 16), (138, 64, 64, 128)])
 def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
     """Regression for a WAR race of the LDS pipeline: a raw s_barrier let waves pass with fragment reads still in
     flight while the next DMA overwrote their ring slot (rare corrupted tiles once 16 waves share a CU).  A full-chip
@@ -252,7 +253,7 @@ def test_conv_result_is_independent_of_tile_variant_and_image_count(cin, cout, h
     full = ops.conv_igemm(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res)
     from multiagentperception_amd._native import W2CError
     tried = 0
-    for v in (0, 3, 6, 8, 30, 36, 38, 50):
+    for v in (0, 3, 6, 8, 30, 36, 38, 50, 130, 136, 138):
         try:
             y = ops.conv_igemm(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, variant=v)
         except W2CError:
@@ -621,3 +622,25 @@ def test_upsample32_argmax_confusion_equals_separate_steps():
         keep = gt < 11
         want = np.bincount((11 * gt[keep] + lab.cpu()[keep].long()).numpy(), minlength=121)
         np.testing.assert_array_equal(hist.cpu().numpy(), 2 * want)
+
+
+@pytest.mark.parametrize("cin,cout,hw,M,G", [(64, 128, 64, 5, 2), (128, 256, 32, 20, 2), (256, 512, 16, 20, 2), (256, 512, 32, 3, 1),
+                                            (64, 128, 18, 2, 1)])
+def test_stride2_block_front_in_one_launch_equals_the_two_convs(cin, cout, hw, M, G):
+    """w2c_conv_s2_block (conv1 3x3/s2 + downsample 1x1/s2 from one staged input) == the two separate launches, bit for bit, for
+    every tile variant; odd map sizes exercise the padding at both borders."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(cin + cout + hw + M)
+    x = torch.randn(M, hw, hw, G * cin + 64, generator=gen).to(BF16).to(_dev())          # extra channels: x_ch_off / stride
+    w3 = (torch.randn(G, cout, 9 * cin, generator=gen) * (2.0 / (9 * cin)) ** 0.5).to(BF16).to(_dev())
+    w1 = (torch.randn(G, cout, cin, generator=gen) * (2.0 / cin) ** 0.5).to(BF16).to(_dev())
+    sc3, sc1 = [(torch.rand(G * cout, generator=gen) + 0.5).to(_dev()) for _ in range(2)]
+    sh3, sh1 = [(torch.randn(G * cout, generator=gen) * 0.1).to(_dev()) for _ in range(2)]
+    t_ref = ops.conv_igemm(x, 64, cin, w3, cout, 3, 2, G, sc3, sh3, relu=True)
+    i_ref = ops.conv_igemm(x, 64, cin, w1, cout, 1, 2, G, sc1, sh1, relu=False)
+    for v in (-1, 0, 3, 6):
+        t, t8, idt = ops.conv_s2_block(x, 64, cin, w3, sc3, sh3, w1, sc1, sh1, cout, G, variant=v)
+        assert t8 is None and torch.equal(t, t_ref) and torch.equal(idt, i_ref), "variant %d" % v
+    t, t8, idt = ops.conv_s2_block(x, 64, cin, w3, sc3, sh3, w1, sc1, sh1, cout, G, t_bf16=False, t_fp8_scale=0.03)
+    _, t8_ref = ops.conv_fp8(x, 64, cin, w3, cout, 3, 2, G, sc3, sh3, relu=True, out_bf16=False, out_fp8_scale=0.03)
+    assert t is None and torch.equal(t8, t8_ref) and torch.equal(idt, i_ref)
