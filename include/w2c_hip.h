@@ -162,6 +162,20 @@ int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int W, int Cin,
                       uint16_t* idt_bf16, int idt_cstride,
                       const void* zero_page, int variant, w2c_stream_t stream);
 
+/* ---- SURVEY 8f rank 3 (training backward, first stage): gradients of the path's 3x3 / 1x1 convolutions
+ * (nn.Conv2d under loss.backward(), trainer.py:669-673).
+ * Weight gradient: dw[g][co][tap][ci] = sum_p dy[p][g*Cout+co] * x[p @ tap][g*Cin+ci], f32, the layout of the packed
+ * weights ([groups][Cout][ksize*ksize][Cin]).  x : the conv's bf16 NHWC input; dy : bf16 NHWC gradient of its output.
+ * Cin, Cout multiples of 64.  Deterministic (segment partials in `workspace`, summed in order by a second launch).
+ * Input gradient: a stride-1 conv's dx is w2c_conv_igemm_bf16 of dy with the flipped, transposed weights
+ * ([Cin][2-ky][2-kx][Cout]); a stride-2 conv's is the same applied to w2c_zero_insert2_bf16(dy) (dy on the even
+ * positions of the input grid, zeros elsewhere). */
+long long w2c_conv_wgrad_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride, int groups);
+int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                        const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride, int groups,
+                        float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream);
+int w2c_zero_insert2_bf16(const uint16_t* dy, int M, int Ho, int Wo, int C, uint16_t* u, int H, int W, w2c_stream_t stream);
+
 /* Unit-test probes of the two fp8 primitives: c[32][32] f32 = a[32][64] . b[32][64]^T (e4m3, one MX-scaled MFMA with
  * unit block scales); y[n] = e4m3(x[n]) as the conv epilogues pack it (round to nearest even, saturating). */
 int w2c_debug_mx_mfma(const uint8_t* a, const uint8_t* b, float* c, w2c_stream_t stream);

@@ -515,10 +515,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 // one barrier per tap, counted vmcnt, patch double-buffered across channel chunks.
 // LDS patch image: one 128-B row per patch pixel, 16-B chunk c of pixel q at c ^ ((q>>1)&7) -- the
 // ds_read_b128 lane groups see 16 consecutive pixels (mod 16 distinct) => conflict-free for TW=32.
-// PIPE: the fragment reads of K-step t+1 are issued BEFORE the MFMAs of K-step t (two register sets), so the LDS round trip
-// of a step runs under the previous step's matrix work instead of in front of its own; the barrier at the top of iteration t
-// then certifies tile t+1, and the weight ring holds STAGES tiles in flight instead of STAGES-1 in the same LDS.
-template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB, bool F8 = false, bool PIPE = false>
+// (Measured and rejected in round 2, profiles/r02_conv_experiments.txt: a software-pipelined form that issues the fragment
+//  reads of K-step t+1 before the MFMAs of K-step t from a second register set.  Correct and bit-identical, but the second
+//  set costs 64-124 registers -- 92 -> 156 / 176 -> 300 -- i.e. ONE workgroup per CU instead of two, and the co-resident
+//  workgroup is what hides this kernel's latencies: layer2 55 -> 84 us, layer3 53 -> 99 us, layer4 58 -> 92 us.)
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB, bool F8 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
     constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;  // operand bytes per element / channels per 128-byte K-step
@@ -730,53 +731,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #ifdef W2C_PHASE_TIMING
     long long ph[5] = {0, 0, 0, 0, 0};
 #endif
-    if constexpr (PIPE) {
-        // ring of STAGES slots, tile t in slot t % STAGES; iteration t: [tile t+1 landed] barrier -> DMA tile t+STAGES into
-        // the slot tile t was read from (its reads were drained by the barrier's lgkmcnt(0)) -> read tile t+1's fragments
-        // -> MFMAs of tile t from the registers read one iteration earlier.
-        issue_patch(0, 0);
-#pragma unroll
-        for (int s = 0; s < STAGES; ++s) issue_b(s);           // KT >= 9 > STAGES
-        wait_vmcnt<(STAGES - 1) * B_INSTR>();                   // patch(0) and tile 0 (older than tiles 1..STAGES-1)
-        pipeline_barrier();
-        dbg_stamp(p, 1);
-        load_frags(fr0, patch0, bring, 0, 0);
-        int nx = (1 == STAGES) ? 0 : 1;                         // slot of tile t+1
-        int wr = 0;                                             // slot of tile t (= where tile t+STAGES goes)
-        int t = 0;
-        for (int cc = 0; cc < nchunks; ++cc) {
-            const char* patch = patch0 + (PB == 2 ? (cc & 1) : 0) * PATCH_BYTES;
-            const char* patch_n = patch0 + (PB == 2 ? ((cc + 1) & 1) : 0) * PATCH_BYTES;
-            const bool more = cc + 1 < nchunks;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap, ++t) {
-                // tile t+1 (and, when it opens chunk cc+1, patch(cc+1): older than that tile) must have landed.  Younger
-                // loads allowed in flight: tiles t+2..t+STAGES-1, plus patch(cc+1) while it is younger than tile t+1
-                // (issued at tap 0 right after tile t0+STAGES).
-                if (t + 1 < KT) {
-                    if (t + STAGES - 1 < KT) {
-                        if (more && tap >= 1 && tap <= STAGES - 1) wait_tiles_and_patch(KS2{});
-                        else wait_vmcnt<(STAGES - 2) * B_INSTR>();
-                    } else {
-                        wait_vmcnt<0>();
-                    }
-                }
-                pipeline_barrier();
-                if (t + STAGES < KT) issue_b(wr);
-                if (tap == 0 && more) issue_patch(cc + 1, (cc + 1) & 1);
-                if (t + 1 < KT) {
-                    if (tap < 8) load_frags(fr1, patch, bring + nx * B_BYTES, ((tap + 1) / 3) * PW + ((tap + 1) % 3), (tap + 1) % 3);
-                    else load_frags(fr1, patch_n, bring + nx * B_BYTES, 0, 0);
-                }
-                mfma_all(fr0);
-                fr0 = fr1;                                      // renamed away inside the unrolled taps; a move per chunk
-                nx = (nx + 1 == STAGES) ? 0 : nx + 1;
-                wr = (wr + 1 == STAGES) ? 0 : wr + 1;
-            }
-        }
-        __syncthreads();
-        dbg_stamp(p, 2);
-    } else {
     issue_patch(0, 0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_b(s);           // KT >= 9 > STAGES-1
@@ -832,7 +786,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     }
     __syncthreads();     // fenced: the epilogue's staging stores must not be hoisted above this barrier
     dbg_stamp(p, 2);
-    }
 #ifdef W2C_PHASE_TIMING
     if (p.dbg && (threadIdx.x & 63) == 0) {          // lane 0 of every wave: [WG][wave][5] after the 4 stamps region
         unsigned long long* o = p.dbg + (1u << 19) + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 5;
@@ -1234,7 +1187,7 @@ int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
 }
 
 
-template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2, bool F8 = false, bool PIPE = false>
+template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB = 2, bool F8 = false>
 int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int CK = OpT<F8>::CK;
     if (a.ks != 3 || a.stride != 1 || a.Cin % CK != 0 || a.Cout % BN != 0 || a.H % TH != 0 || a.W % TW != 0)
@@ -1250,12 +1203,12 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8, PIPE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8, PIPE>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -1426,10 +1379,6 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
-        // PIPE forms of 30 / 36 / 38: next step's fragment reads under this step's MFMAs
-        case 130: return launch_patch<8, 16, 128, 2, 2, 2, 2, false, true>(a, groups, s);
-        case 136: return launch_patch<8, 16, 64, 4, 2, 3, 2, false, true>(a, groups, s);
-        case 138: return launch_patch<8, 16, 64, 2, 2, 2, 1, false, true>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -1445,10 +1394,6 @@ int launch_variant_f8(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 36: return launch_patch<8, 16, 64, 4, 2, 3, 2, true>(a, groups, s);
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1, true>(a, groups, s);      // Cin == 128: one chunk
         case 40: return launch_patch<8, 16, 128, 2, 2, 2, 1, true>(a, groups, s);     // Cin == 128, 128 channels per tile
-        case 130: return launch_patch<8, 16, 128, 2, 2, 2, 2, true, true>(a, groups, s);
-        case 136: return launch_patch<8, 16, 64, 4, 2, 3, 2, true, true>(a, groups, s);
-        case 138: return launch_patch<8, 16, 64, 2, 2, 2, 1, true, true>(a, groups, s);
-        case 140: return launch_patch<8, 16, 128, 2, 2, 2, 1, true, true>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }

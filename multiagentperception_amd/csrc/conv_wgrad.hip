@@ -1,0 +1,236 @@
+// conv_wgrad.hip -- weight gradient of the path's 3x3 / 1x1 convolutions (the backward of
+// trainer.py:669-673's loss.backward() for nn.Conv2d, models/utils.py:87-120, backbone.py:66-69,150-154).
+//
+//   dW[g][co][tap][ci] = sum over output pixels p of  dY[p][g*Cout + co] * X[p @ tap][g*Cin + ci]
+//
+// A GEMM whose reduction runs over PIXELS -- the outer dimension of the NHWC tensors -- while an MFMA operand lane wants
+// 8 consecutive reduction elements.  Tiles are staged in LDS exactly as the forward kernel stages them ([pixel][64 channels],
+// 128-byte rows, LDS-DMA with buffer addressing, out-of-image taps = out-of-range offsets -> zeros) and read back
+// TRANSPOSED by gfx950's ds_read_b64_tr_b16: within a 16-lane group, lane 4r+q supplies the address of 4 contiguous
+// channels of pixel r; lane l receives channel l of pixels 0..3 -- the k-contiguous fragment, no shuffles.
+// Workgroup (4 waves, 2 x 2): one (group, 64 co, 64 ci) weight tile over one segment of the output pixels, all taps:
+// per 64-pixel block the dY tile is staged once (its fragments stay in registers across the taps) and the X tile once per
+// tap (double-buffered); 9 accumulator sets per wave.  Segments' partial tiles go to a workspace and are summed in segment
+// order by a second launch (deterministic -- no float atomics).
+#include "w2c_common.h"
+
+namespace {
+
+struct WgradArgs {
+    const uint16_t* x;
+    const uint16_t* dy;
+    float* ws;         // [nseg][G][Cout][taps][Cin]
+    float* dw;         // [G][Cout][taps][Cin]
+    int M, H, W, Cin, xcs;
+    int Ho, Wo, Cout, ycs;
+    int ks, stride, pad;
+    int rows;          // M*Ho*Wo
+    int nseg, blocks_per_seg;   // 64-pixel blocks per segment
+    int nct_o, nct_i;  // 64-channel tiles along Cout / Cin
+};
+
+template <int N>
+__device__ __forceinline__ void wg_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// transposed fragment: 32 channels x 16 pixels of a [pixel][64 ch] tile (128-B rows) -> MFMA operand (8 k per lane).
+// (The builtin, not inline asm: the compiler then tracks lgkmcnt for the two reads.)
+typedef __attribute__((ext_vector_type(4))) short w2c_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short w2c_s16x8_t;
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int pix0, int cbase, int lane) {
+    const int lhi = lane >> 5, g16 = (lane >> 4) & 1, r = (lane & 15) >> 2, q = lane & 3;
+    const char* a = tile + (pix0 + 8 * lhi + r) * 128 + (cbase + 16 * g16 + 4 * q) * 2;
+    const w2c_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2c_s16x4_t*)(a));
+    const w2c_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2c_s16x4_t*)(a + 512));
+    const w2c_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BP = 64;                       // pixels per block
+    __shared__ __attribute__((aligned(16))) char smem[BP * 128 * 3];      // dY tile | X tile x 2
+    char* const Ys = smem;
+    char* const Xs = smem + BP * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = blockIdx.z;
+    const int seg = blockIdx.y;
+    const int to = blockIdx.x / p.nct_i, ti = blockIdx.x - to * p.nct_i;
+    const int lrow = lane >> 3, lpos = lane & 7;
+
+    const char* xg = reinterpret_cast<const char*>(p.x) + ((size_t)g * p.Cin + ti * 64) * 2;
+    const char* yg = reinterpret_cast<const char*>(p.dy) + ((size_t)g * p.Cout + to * 64) * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(yg), 0, (int)((size_t)p.rows * p.ycs * 2), 0x00020000);
+
+    f32x16_t acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int b_begin = seg * p.blocks_per_seg;
+    const int nblocks = (p.rows + BP - 1) / BP;
+    const int b_end = min(nblocks, b_begin + p.blocks_per_seg);
+    for (int blk = b_begin; blk < b_end; ++blk) {
+        const int p0 = blk * BP;
+        // this lane's two pixel rows of the block (DMA instruction j moves rows (wave + 4j)*8 + lrow)
+        int iy0[2], ix0[2];
+        unsigned ybase[2];
+        int xbase[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pr = p0 + (wave + 4 * j) * 8 + lrow;
+            if (pr < p.rows) {
+                const int hw = p.Ho * p.Wo;
+                const int m = pr / hw, rem = pr - m * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                iy0[j] = oy * p.stride - p.pad;
+                ix0[j] = ox * p.stride - p.pad;
+                ybase[j] = (unsigned)((size_t)pr * p.ycs * 2 + lpos * 16);
+                xbase[j] = (int)((((long)m * p.H + iy0[j]) * p.W + ix0[j]) * p.xcs * 2 + lpos * 16);
+            } else {
+                iy0[j] = -100000; ix0[j] = 0; ybase[j] = 0x80000000u; xbase[j] = 0;
+            }
+        }
+        auto stage_x = [&](int tap, int buf) {
+            const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap - 3 * (tap / 3);
+            const int tap_off = (ky * p.W + kx) * p.xcs * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned vo = ok ? (unsigned)(xbase[j] + tap_off) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(Xs + buf * (BP * 128) + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0);
+            }
+        };
+        __syncthreads();                                   // previous block's tiles are no longer read
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, W2C_LPTR(Ys + (wave + 4 * j) * 1024), 16, ybase[j], 0, 0, 0);
+        stage_x(0, 0);
+        bf16x8_t ya[4];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            wg_wait_vmcnt<0>();
+            __syncthreads();                               // tile(tap) (and dY) landed for everyone; the other X buffer is free
+            if (tap + 1 < TAPS) stage_x(tap + 1, (tap + 1) & 1);
+            if (tap == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) ya[kk] = tr_frag(Ys, kk * 16, wm * 32, lane);
+            }
+            const char* xt = Xs + (tap & 1) * (BP * 128);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t xb = tr_frag(xt, kk * 16, wn * 32, lane);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[kk], xb, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // partial tile -> workspace: D[i = co][j = ci]; lane holds column ci = l31, rows co = (e&3) + 8(e>>2) + 4 lhi
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const size_t wsz = (size_t)gridDim.z * p.Cout * TAPS * p.Cin;
+    float* out = p.ws + (size_t)seg * wsz + ((size_t)g * p.Cout + to * 64 + wm * 32) * TAPS * p.Cin + ti * 64 + wn * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            out[((size_t)co * TAPS + tap) * p.Cin] = acc[tap][e];
+        }
+#endif
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int nseg) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4_t s = reinterpret_cast<const f32x4_t*>(ws)[i];
+    for (int k = 1; k < nseg; ++k) s += reinterpret_cast<const f32x4_t*>(ws)[(size_t)k * n4 + i];
+    reinterpret_cast<f32x4_t*>(dw)[i] = s;
+}
+
+// dY (stride-2 conv output grid) -> zero-inserted tensor on the input grid: u[m][2oy][2ox] = dy[m][oy][ox], 0 elsewhere;
+// the stride-2 conv's input gradient is then a stride-1 conv of u with the flipped, transposed weights.
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const uint4* __restrict__ dy, uint4* __restrict__ u, int M, int Ho, int Wo, int H,
+                                                           int W, int c8) {
+    const size_t total = (size_t)M * H * W * c8;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int c = (int)(id % c8);
+        size_t t = id / c8;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int m = (int)(t / H);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!(iy & 1) && !(ix & 1) && (iy >> 1) < Ho && (ix >> 1) < Wo)
+            v = dy[(((size_t)m * Ho + (iy >> 1)) * Wo + (ix >> 1)) * c8 + c];
+        u[id] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" long long w2c_conv_wgrad_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride, int groups) {
+    if (M <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % 64 || groups <= 0) return -1;
+    if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return -1;
+    const int pad = ksize == 3 ? 1 : 0;
+    const long rows = (long)M * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+    const long nblocks = (rows + 63) / 64;
+    const long tiles = (long)(Cout / 64) * (Cin / 64) * groups;
+    long nseg = (1536 + tiles - 1) / tiles;                      // ~6 workgroups per CU in total
+    if (nseg > nblocks) nseg = nblocks;
+    if (nseg < 1) nseg = 1;
+    return nseg * (long long)groups * Cout * ksize * ksize * Cin * 4;
+}
+
+extern "C" int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                   const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride, int groups,
+                                   float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !dy || !dw || !workspace) return W2C_E_ARG;
+    const long long need = w2c_conv_wgrad_workspace_bytes(M, H, W, Cin, Cout, ksize, stride, groups);
+    if (need < 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(dw) & 15))
+        return W2C_E_ARG;
+    if (x_cstride < groups * Cin || dy_cstride < groups * Cout || (x_cstride % 8) || (dy_cstride % 8)) return W2C_E_ARG;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.ws = reinterpret_cast<float*>(workspace); a.dw = dw;
+    a.M = M; a.H = H; a.W = W; a.Cin = Cin; a.xcs = x_cstride;
+    a.ks = ksize; a.stride = stride; a.pad = ksize == 3 ? 1 : 0;
+    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    a.Cout = Cout; a.ycs = dy_cstride;
+    if ((size_t)M * H * W * x_cstride * 2 >= (1ull << 31) || (size_t)M * a.Ho * a.Wo * dy_cstride * 2 >= (1ull << 31)) return W2C_E_ARG;
+    a.rows = M * a.Ho * a.Wo;
+    const long per = (long)groups * Cout * ksize * ksize * Cin * 4;
+    a.nseg = (int)(need / per);
+    const int nblocks = (a.rows + 63) / 64;
+    a.blocks_per_seg = (nblocks + a.nseg - 1) / a.nseg;
+    a.nct_o = Cout / 64; a.nct_i = Cin / 64;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(a.nct_o * a.nct_i, a.nseg, groups);
+    if (ksize == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, s, a);
+    int rc = w2c_launch_status();
+    if (rc != W2C_OK) return rc;
+    const long n4 = per / 16;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.ws, dw, n4, a.nseg);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_zero_insert2_bf16(const uint16_t* dy, int M, int Ho, int Wo, int C, uint16_t* u, int H, int W, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!dy || !u || M <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C % 8) || H < 2 * Ho - 1 || W < 2 * Wo - 1 || H > 2 * Ho || W > 2 * Wo)
+        return W2C_E_ARG;
+    const size_t total = (size_t)M * H * W * (C / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint4*>(dy), reinterpret_cast<uint4*>(u), M, Ho, Wo, H, W, C / 8);
+    return w2c_launch_status();
+}

@@ -447,6 +447,15 @@ class CommEngine:
         keys, querys = self.policy_tail(sq)
         return sq, keys, querys
 
+    def encode_from_stem(self, s0):
+        """Everything between the pooled stem output and the communication graph -> (sq, tproj, queries).
+        (Measured and rejected, profiles/r02_concurrency_experiments.txt: running the policy encoder's layer4 alone first so
+        that the policy tail overlaps the value encoder's layer4 on a second stream -- 1.2988 vs 1.3024 ms, no gain: the
+        tail's launches are inefficient, not idle, and a concurrent kernel only shares their CUs.)"""
+        sq = self.trunk.after_stem(s0)
+        keys, querys = self.policy_tail(sq)
+        return sq, keys, querys
+
     def graph_and_low(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
         """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decoder convs
         (everything up to the low-resolution logits)."""
@@ -474,7 +483,7 @@ class CommEngine:
         else:
             finish = lambda low: ops.upsample_bilinear32(low, self.n_classes)           # noqa: E731
         if not use_graph:
-            sq, keys, querys = self.encode(x, N)
+            sq, keys, querys = self.encode_from_stem(self.trunk.stem(x, N))
             low, prob, action, nnz = self.graph_and_low(sq, keys, querys, B, N, 0, N, mode)
             return finish(low), prob, action, nnz
         key = (tuple(x.shape), str(x.dtype), mode)
@@ -495,8 +504,7 @@ class CommEngine:
         dev = x.device
 
         def middle(s0):
-            sq = self.trunk.after_stem(s0)
-            keys, querys = self.policy_tail(sq)
+            sq, keys, querys = self.encode_from_stem(s0)
             return self.graph_and_low(sq, keys, querys, B, N, 0, N, mode)
 
         side = torch.cuda.Stream(device=dev)

@@ -18,18 +18,20 @@ ResNet-18 key names: third-party pretrainedmodels -> torchvision resnet18.
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..train_ops import Conv2dHip
+
 
 class BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.conv1 = Conv2dHip(cin, cout, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(cout)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.conv2 = Conv2dHip(cout, cout, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(cout)
         self.downsample = None
         if stride != 1 or cin != cout:
-            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+            self.downsample = nn.Sequential(Conv2dHip(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
         self.stride = stride
 
     def forward(self, x):
@@ -44,7 +46,7 @@ class ResNet18(nn.Module):
 
     def __init__(self, num_classes=1000):
         super().__init__()
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.conv1 = Conv2dHip(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
@@ -78,7 +80,7 @@ class conv2DBatchNormRelu(nn.Module):
     def __init__(self, in_channels, n_filters, k_size, stride, padding, bias=True):
         super().__init__()
         self.cbr_unit = nn.Sequential(
-            nn.Conv2d(int(in_channels), int(n_filters), kernel_size=k_size, padding=padding, stride=stride, bias=bias),
+            Conv2dHip(int(in_channels), int(n_filters), kernel_size=k_size, padding=padding, stride=stride, bias=bias),
             nn.BatchNorm2d(int(n_filters)), nn.ReLU(inplace=True))
 
     def forward(self, x):
@@ -96,11 +98,11 @@ class simple_decoder(nn.Module):
     def __init__(self, n_classes=21, in_channels=512):
         super().__init__()
         self.in_channels = in_channels
-        self.pred = nn.Sequential(nn.Conv2d(in_channels, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
-                                  nn.Conv2d(256, n_classes, kernel_size=3, padding=1))
+        self.pred = nn.Sequential(Conv2dHip(in_channels, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+                                  Conv2dHip(256, n_classes, kernel_size=3, padding=1))
 
     def forward(self, x):
-        y = self.pred(x)
+        y = self.pred(x).float()                    # (bf16 under the HIP training backend; the upsample and the loss are f32)
         return F.interpolate(y, size=(x.shape[2] * 32, x.shape[3] * 32), mode="bilinear", align_corners=False)
 
 
@@ -162,7 +164,7 @@ class _mlp_head(nn.Module):
                                 nn.ReLU(inplace=True), nn.Linear(128, out_size))
 
     def forward(self, x):
-        return self.fc(x.reshape(-1, self.n_feat))
+        return self.fc(x.reshape(-1, self.n_feat).float())
 
 
 class km_generator(_mlp_head):

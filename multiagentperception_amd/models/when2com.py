@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine as _engine
+from .. import train_ops
 from .._native import W2CError
 from . import blocks
 
@@ -84,8 +85,10 @@ class Single_agent(_EngineCacheMixin, nn.Module):
         self._init_engine_cache()
 
     def forward(self, inputs):
-        if self.training:
-            return self.decoder(self.encoder(inputs))                 # stock-op autograd path (see module doc)
+        if self.training:                                             # autograd path; convs on the HIP kernels (train_ops)
+            if inputs.is_cuda and train_ops.train_backend() == "hip":
+                inputs = inputs.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            return self.decoder(self.encoder(inputs))
         eng = self._engine_for(inputs, _engine.SingleEngine)
         with torch.no_grad():
             pred, _, _ = eng.forward(inputs.contiguous().float())
@@ -198,7 +201,9 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
         num_connect = self.agent_num - 1 if inference == "softmax" else int(nnz.sum().item()) / (self.agent_num * B)
         return labels, prob, action, num_connect
 
-    # ---- train-mode path: stock PyTorch ops + autograd (outside the accelerated scope) ------
+    # ---- train-mode path: the reference's layer graph under autograd; the 3x3 / 1x1 convolutions
+    # (97 % of the FLOPs) run on the HIP kernels forward AND backward (train_ops.Conv2dHip), train-mode BatchNorm over
+    # the agent-concatenated batch (agent.py:1108-1111), ReLU, pooling, heads and attention on stock PyTorch-ROCm ops ------
     def _forward_train_stock_ops(self, inputs, training, MO_flag, inference):
         if not training:
             raise W2CError("module is in train() mode but forward(training=False) was requested; call .eval() "
@@ -207,7 +212,9 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
             raise W2CError("MO_flag=False is not supported (see eval path)")
         B, N = inputs.shape[0], self.agent_num
         unified = torch.cat(self.divide_inputs(inputs), 0)
-        feat_maps = self.u_encoder(unified)
+        if inputs.is_cuda and train_ops.train_backend() == "hip":
+            unified = unified.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)   # bf16 NHWC activations
+        feat_maps = self.u_encoder(unified).float()
         val_mat = torch.stack([feat_maps[B * i:B * (i + 1)] for i in range(N)], 1)
         qk = self.query_key_net(unified)
         keys = self.key_net(qk)

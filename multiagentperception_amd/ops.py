@@ -377,6 +377,45 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
     return t16, t8, idt
 
 
+_wgrad_ws = {}
+
+
+def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups):
+    """dW f32 [G, cout, ksize*ksize*cin] of the conv that maps x (bf16 NHWC, channels [x_ch_off, +G*cin)) to an output whose
+    gradient is dy (bf16 NHWC [M,Ho,Wo,G*cout]).  include/w2c_hip.h w2c_conv_wgrad_bf16."""
+    dev = _need_gpu(x, dy)
+    if x.dtype != BF16 or dy.dtype != BF16:
+        raise W2CError("conv_wgrad: bf16 tensors expected")
+    M, H, W, xcs = x.shape
+    pad = 1 if ksize == 3 else 0
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    if tuple(dy.shape[:3]) != (M, Ho, Wo) or dy.shape[3] < groups * cout or x_ch_off < 0 or x_ch_off + groups * cin > xcs:
+        raise W2CError("conv_wgrad: geometry mismatch")
+    need = _native.lib().w2c_conv_wgrad_workspace_bytes(M, H, W, cin, cout, ksize, stride, groups)
+    if need < 0:
+        raise W2CError("conv_wgrad: unsupported shape (Cin, Cout multiples of 64; 3x3 or 1x1; stride 1 or 2)")
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(int(need), 32 << 20), dtype=torch.uint8, device=dev)
+        _wgrad_ws[key] = ws
+    dw = torch.empty((groups, cout, ksize * ksize * cin), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_wgrad_bf16(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(dy), cout, dy.shape[3], ksize,
+                                                stride, groups, _p(dw), _p(ws), ws.numel(), _stream(dev)), "w2c_conv_wgrad_bf16")
+    return dw
+
+
+def zero_insert2(dy, H, W):
+    """dy bf16 NHWC [M,Ho,Wo,C] -> [M,H,W,C] with dy at the even positions, zeros elsewhere (stride-2 dgrad helper)."""
+    dev = _need_gpu(dy)
+    M, Ho, Wo, C = dy.shape
+    u = torch.empty((M, H, W, C), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_zero_insert2_bf16(_p(dy), M, Ho, Wo, C, _p(u), H, W, _stream(dev)), "w2c_zero_insert2_bf16")
+    return u
+
+
 def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
     """y[M,O] = act(x[M,K] W^T + b); x bf16 or f32 (2-D view given by rows/k/x_stride)."""
     dev = _need_gpu(x, w, b)

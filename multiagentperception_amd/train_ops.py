@@ -1,0 +1,114 @@
+"""Training-mode convolutions on the HIP kernels (first stage).
+
+``trainer.py:669-673`` runs ``model.train(); outputs = model(images, training=True, ...); loss.backward()``.  Under
+``module.train()`` the modules of ``models/blocks.py`` execute their ordinary layer graph (train-mode BatchNorm over the
+agent-concatenated batch ``agent.py:1108-1111``, ReLU, residual adds, pooling, heads, attention: stock PyTorch-ROCm ops with
+autograd), but every 3x3 / 1x1 convolution the kernels cover -- all of ResNet-18's layer1..4 in both encoders, the
+squeezers, policy conv1..5, the decoder's first conv: 97 % of the training FLOPs -- goes through ``conv2d_hip``:
+
+  forward   w2c_conv_igemm_bf16 (bf16 operands, f32 accumulate, bias in the epilogue)
+  dX        the same kernel on dY with the flipped, transposed weights (stride 2: on the zero-inserted dY)
+  dW        w2c_conv_wgrad_bf16 (MFMA over pixels via transposed LDS reads, deterministic)
+  dbias     a column sum
+
+Activations travel as bf16 NHWC (torch ``channels_last``), master weights stay f32 (a mixed-precision step).  The 7x7 stem
+(Cin = 3) and the decoder's 256 -> 11 head (Cout = 11) are outside the kernels' shape rules and are ASSIGNED to the stock
+convolution -- a documented scope line, not a fallback: a supported conv on a GPU tensor raises if the library is missing.
+``set_train_backend("stock")`` (or W2C_TRAIN_BACKEND=stock) runs everything on stock ops, e.g. as the gradient oracle in
+tests/test_train_gpu.py.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+BF16 = torch.bfloat16
+_backend = os.environ.get("W2C_TRAIN_BACKEND", "hip")
+
+
+def set_train_backend(name):
+    global _backend
+    if name not in ("hip", "stock"):
+        raise ValueError("train backend: 'hip' or 'stock'")
+    _backend = name
+
+
+def train_backend():
+    return _backend
+
+
+def _nhwc_bf16(x):
+    """logical NCHW tensor (any dtype / memory format) -> contiguous bf16 NHWC [M,H,W,C] (no copy when x already is bf16
+    channels_last)."""
+    y = x.permute(0, 2, 3, 1)
+    if y.dtype != BF16:
+        y = y.to(BF16)
+    return y.contiguous()
+
+
+def _pack_fwd(weight):
+    co = weight.shape[0]
+    return weight.detach().permute(0, 2, 3, 1).reshape(1, co, -1).to(BF16).contiguous()          # [1][Cout][tap][Cin]
+
+
+def _pack_dgrad(weight):
+    ci = weight.shape[1]
+    return weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(1, ci, -1).to(BF16).contiguous()   # [1][Cin][2-ky,2-kx][Cout]
+
+
+class _Conv2dHipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        cout, cin, k, _ = weight.shape
+        xh = _nhwc_bf16(x)
+        dev = xh.device
+        ones = torch.ones(cout, device=dev)
+        shift = bias.detach().float() if bias is not None else torch.zeros(cout, device=dev)
+        y = ops.conv_igemm(xh, 0, cin, _pack_fwd(weight), cout, k, stride, 1, ones, shift, relu=False)
+        ctx.save_for_backward(xh, weight)
+        ctx.stride, ctx.has_bias, ctx.in_dtype = stride, bias is not None, x.dtype
+        y = y.permute(0, 3, 1, 2)
+        return y if x.dtype == BF16 else y.to(x.dtype)        # bf16 in -> bf16 out (the models' train path); else the caller's dtype
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, weight = ctx.saved_tensors
+        cout, cin, k, _ = weight.shape
+        M, H, W, _ = xh.shape
+        gyh = _nhwc_bf16(gy)
+        dev = xh.device
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            src = gyh if ctx.stride == 1 else ops.zero_insert2(gyh, H, W)
+            dxh = ops.conv_igemm(src, 0, cout, _pack_dgrad(weight), cin, k, 1, 1, torch.ones(cin, device=dev),
+                                 torch.zeros(cin, device=dev), relu=False)
+            dx = dxh.permute(0, 3, 1, 2)
+            if dx.dtype != ctx.in_dtype:
+                dx = dx.to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(xh, 0, cin, gyh, cout, k, ctx.stride, 1).reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gyh.float().sum(dim=(0, 1, 2))
+        return dx, dw, db, None
+
+
+def hip_supported(conv):
+    k, s = conv.kernel_size, conv.stride
+    return (k[0] == k[1] and k[0] in (1, 3) and s[0] == s[1] and s[0] in (1, 2) and conv.padding == (k[0] // 2, k[0] // 2)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+
+
+class Conv2dHip(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state_dict keys) whose TRAIN-mode forward runs on the HIP conv kernels when the
+    backend is "hip", the input is on the GPU and the shape is one the kernels cover; see the module docstring."""
+
+    def forward(self, x):
+        if _backend == "hip" and x.is_cuda and hip_supported(self) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            return _Conv2dHipFn.apply(x, self.weight, self.bias, self.stride[0])
+        if x.dtype != self.weight.dtype:            # bf16 activations meet f32 master weights in the two stock convs
+            return F.conv2d(x, self.weight.to(x.dtype), None if self.bias is None else self.bias.to(x.dtype), self.stride,
+                            self.padding, self.dilation, self.groups)
+        return super().forward(x)

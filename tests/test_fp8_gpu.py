@@ -143,7 +143,7 @@ def test_conv_fp8_result_is_independent_of_variant_and_image_count(cin, cout, hw
     res = torch.randn(M, ho, ho, G * cout, generator=gen).to(BF16).to(_dev())
     f16, f8 = ops.conv_fp8(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, out_fp8_scale=0.05)
     tried = 0
-    for v in (0, 3, 6, 36, 38, 40, 130, 136, 138, 140):
+    for v in (0, 3, 6, 36, 38, 40):
         try:
             a16, a8 = ops.conv_fp8(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, out_fp8_scale=0.05, variant=v)
         except W2CError:

@@ -211,8 +211,7 @@ def test_conv_splitk_matches_fp32_and_is_deterministic(case):
 
 
 @pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128),
-                                                 (36, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16),
-                                                 (130, 128, 128, 64), (136, 256, 256, 32), (136, 512, 512, 16), (138, 64, 64, 128)])
+                                                 (36, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16)])
 def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
     """Regression for a WAR race of the LDS pipeline: a raw s_barrier let waves pass with fragment reads still in
     flight while the next DMA overwrote their ring slot (rare corrupted tiles once 16 waves share a CU).  A full-chip
@@ -253,7 +252,7 @@ def test_conv_result_is_independent_of_tile_variant_and_image_count(cin, cout, h
     full = ops.conv_igemm(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res)
     from multiagentperception_amd._native import W2CError
     tried = 0
-    for v in (0, 3, 6, 8, 30, 36, 38, 50, 130, 136, 138):
+    for v in (0, 3, 6, 8, 30, 36, 38, 50):
         try:
             y = ops.conv_igemm(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, variant=v)
         except W2CError:

@@ -1,0 +1,149 @@
+"""GPU: training backward, first stage -- the conv gradients on the HIP kernels, against PyTorch autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+WGRAD_CASES = [
+    # M, H, W, Cin, Cout, ks, stride, groups
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 16, 16, 64, 128, 3, 1, 2),          # 2 groups
+    (2, 32, 32, 64, 128, 3, 2, 1),          # stride 2
+    (5, 10, 6, 128, 64, 3, 1, 1),           # 300 pixels: ragged 64-pixel blocks, non-square
+    (20, 4, 4, 256, 256, 3, 2, 1),          # policy conv5: 2x2 output maps
+    (3, 8, 8, 128, 256, 1, 2, 2),           # 1x1 s2 downsample
+    (1, 64, 64, 64, 64, 1, 1, 1),
+    (20, 32, 32, 128, 128, 3, 1, 2),        # many segments
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[str(c) for c in WGRAD_CASES])
+def test_conv_wgrad_matches_autograd(case):
+    from multiagentperception_amd import ops
+    M, H, W, cin, cout, ks, stride, G = case
+    gen = torch.Generator().manual_seed(sum(case))
+    pad = ks // 2
+    x = torch.randn(M, G * cin, H, W, generator=gen).to(BF16).float()
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    dy = torch.randn(M, G * cout, Ho, Wo, generator=gen).to(BF16).float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF16).to(_dev())
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF16).to(_dev())
+    first = ops.conv_wgrad(xd, 0, cin, dyd, cout, ks, stride, G)
+    again = ops.conv_wgrad(xd, 0, cin, dyd, cout, ks, stride, G)
+    torch.cuda.synchronize()
+    assert torch.equal(first, again)                                   # deterministic (no float atomics)
+    got = first.cpu().reshape(G, cout, ks, ks, cin).permute(0, 1, 4, 2, 3)   # [G][co][ci][ky][kx]
+    for g in range(G):
+        w = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x[:, g * cin:(g + 1) * cin].double(), w, None, stride=stride, padding=pad)
+        y.backward(dy[:, g * cout:(g + 1) * cout].double())
+        ref = w.grad.float()
+        scale = float(ref.abs().max())
+        np.testing.assert_allclose(got[g].numpy(), ref.numpy(), atol=2e-4 * scale + 1e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,hw,bias", [(64, 64, 3, 1, 16, False), (64, 128, 3, 2, 32, False), (128, 256, 1, 2, 16, False),
+                                                        (512, 256, 3, 1, 8, True), (256, 256, 3, 2, 8, True)])
+def test_conv2d_hip_function_gradients_match_stock_conv(cin, cout, ks, stride, hw, bias):
+    """train_ops.Conv2dHip (forward + dX + dW + dbias on the HIP kernels) vs the same nn.Conv2d on stock ops in f32."""
+    from multiagentperception_amd import train_ops
+    gen = torch.Generator().manual_seed(cin + cout + ks + stride)
+    conv = train_ops.Conv2dHip(cin, cout, ks, stride, ks // 2, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (cin * ks * ks)) ** 0.5)
+        conv.weight.copy_(conv.weight.to(BF16).float())
+    conv = conv.to(_dev())
+    x0 = torch.randn(3, cin, hw, hw, generator=gen).to(BF16).float()
+    gy = None
+    outs = {}
+    for backend in ("stock", "hip"):
+        train_ops.set_train_backend(backend)
+        conv.zero_grad()
+        x = x0.to(_dev()).requires_grad_(True)
+        xin = x if backend == "stock" else x.to(BF16).contiguous(memory_format=torch.channels_last)
+        y = conv(xin)
+        if gy is None:
+            gy = torch.randn(y.shape, generator=gen).to(BF16).float().to(_dev())
+        y.float().backward(gy)
+        outs[backend] = (y.float().detach().cpu(), x.grad.cpu(), conv.weight.grad.cpu(), None if not bias else conv.bias.grad.cpu())
+    train_ops.set_train_backend("hip")
+    ys, dxs, dws, dbs = outs["stock"]
+    yh, dxh, dwh, dbh = outs["hip"]
+    assert yh.shape == ys.shape
+    np.testing.assert_allclose(yh.numpy(), ys.numpy(), atol=1e-2, rtol=2 ** -7)                # bf16 output rounding
+    np.testing.assert_allclose(dxh.numpy(), dxs.numpy(), atol=2e-2 * float(dxs.abs().max()), rtol=2 ** -7)
+    np.testing.assert_allclose(dwh.numpy(), dws.numpy(), atol=1e-3 * float(dws.abs().max()) + 1e-4, rtol=1e-3)
+    if bias:
+        np.testing.assert_allclose(dbh.numpy(), dbs.numpy(), atol=1e-3 * float(dbs.abs().max()), rtol=1e-3)
+
+
+def test_zero_insert2_places_dy_on_the_even_grid():
+    from multiagentperception_amd import ops
+    dy = torch.randn(2, 5, 7, 64).to(BF16).to(_dev())
+    for H, W in ((10, 14), (9, 13)):
+        u = ops.zero_insert2(dy, H, W)
+        ref = torch.zeros(2, H, W, 64, dtype=BF16, device=_dev())
+        ref[:, ::2, ::2] = dy[:, :(H + 1) // 2, :(W + 1) // 2]
+        assert torch.equal(u, ref)
+
+
+def _cfg(arch, n, size, query=True):
+    return {"model": dict(arch=arch, agent_num=n, shared_img_encoder="unified", attention="general", sparse=False, query=query,
+                          query_size=32, key_size=1024, enc_backbone="resnet_encoder", dec_backbone="simple_decoder",
+                          feat_squeezer=-1, feat_channel=512), "data": {"img_rows": size, "img_cols": size}}
+
+
+@pytest.mark.parametrize("arch,n,query", [("MIMOcom", 3, True), ("MIMOcomWho", 3, False), ("Single_agent", 1, True)])
+def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
+    """One trainer.py:669-673 step (train(), forward(training=True), cross_entropy2d, backward): loss and parameter gradients with
+    the convs on the HIP kernels (bf16 activations) vs everything on stock f32 ops.  bf16 storage perturbs a BatchNorm-normalised
+    net's gradients by a few percent, so the check is directional: cosine similarity per parameter tensor."""
+    from oracle import filler
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import train_ops
+    b, s = 2, 128
+    torch.manual_seed(0)
+    model = get_model(_cfg(arch, n, s, query), 11)
+    filler.apply_to_module(model)
+    model = model.to(_dev()).train()
+    x = torch.from_numpy(filler.synthetic_frames(b, n, s, s, 31)).to(_dev())
+    labels = torch.from_numpy(filler.synthetic_labels(b * n, s, s, 31)).to(_dev())
+    res = {}
+    for backend in ("stock", "hip"):
+        train_ops.set_train_backend(backend)
+        model.zero_grad()
+        out = model(x) if arch == "Single_agent" else model(x, training=True, MO_flag=True)
+        pred = out if arch == "Single_agent" else out[0]
+        assert pred.dtype == torch.float32 and pred.shape == (b * n, 11, s, s)
+        loss = F.cross_entropy(pred, labels, ignore_index=250)               # loss/loss.py:5-18
+        loss.backward()
+        res[backend] = (float(loss), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None})
+    train_ops.set_train_backend("hip")
+    ls, gs = res["stock"]
+    lh, gh = res["hip"]
+    assert abs(lh - ls) <= 2e-2 * abs(ls), (lh, ls)
+    assert gs.keys() == gh.keys()
+    worst, n_checked, dot, na, nr = (1.0, ""), 0, 0.0, 0.0, 0.0
+    for k in gs:
+        a, r = gh[k].reshape(-1).double(), gs[k].reshape(-1).double()
+        dot, na, nr = dot + float(torch.dot(a, r)), na + float(a.norm() ** 2), nr + float(r.norm() ** 2)
+        if float(r.norm()) < 1e-6 * r.numel() ** 0.5:
+            continue
+        cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-30))
+        worst = min(worst, (cos, k))
+        n_checked += 1
+        # the deepest tensors (the 7x7 stems, ~20 bf16-stored layers below the loss) collect the most rounding noise:
+        # measured 0.95 there, >= 0.98 from layer2 up
+        assert cos >= 0.90, (k, cos)
+    total = dot / (na ** 0.5 * nr ** 0.5)
+    print("%s: loss stock %.5f hip %.5f; %d parameter tensors, whole-gradient cosine %.4f, worst tensor %.4f (%s)" % (
+        arch, ls, lh, n_checked, total, worst[0], worst[1]))
+    assert total >= 0.97

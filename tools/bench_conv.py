@@ -30,9 +30,8 @@ LAYERS = [
 VALID = {  # variant -> (BM, BN, BK)
     0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
     30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64),
-    130: (128, 128, 64), 136: (128, 64, 64), 138: (128, 64, 64),
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 130: (8, 16), 136: (8, 16), 138: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16)}
 
 
 def main():
