@@ -8,6 +8,7 @@ import torch.nn as nn
 from .. import engine as _engine
 from .._native import W2CError
 from . import blocks
+from .. import train_ops
 from .when2com import _EngineCacheMixin
 
 
@@ -67,12 +68,15 @@ class _SRMSBase(_EngineCacheMixin, nn.Module):
     def _encode_stock(self, inputs):
         B = inputs.shape[0]
         unified = torch.cat(self.divide_inputs(inputs), 0)
+        if inputs.is_cuda and train_ops.bf16_activations():       # convs on the HIP kernels, bf16 NHWC activations (train_ops)
+            unified = unified.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         if self.shared_img_encoder == "unified":
             feat = self.u_encoder(unified)
         elif self.shared_img_encoder == "only_normal_agents":
             feat = torch.cat((self.degarded_encoder(unified[:B]), self.normal_encoder(unified[B:])), 0)
         else:
             feat = torch.cat([getattr(self, "encoder%d" % (i + 1))(unified[B * i:B * (i + 1)]) for i in range(5)], 0)
+        feat = feat.float()
         vals = torch.stack([feat[B * i:B * (i + 1)] for i in range(5)], 1)
         qk = self.query_key_net(unified)
         keys = self.key_net(qk)

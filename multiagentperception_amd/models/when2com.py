@@ -86,7 +86,7 @@ class Single_agent(_EngineCacheMixin, nn.Module):
 
     def forward(self, inputs):
         if self.training:                                             # autograd path; convs on the HIP kernels (train_ops)
-            if inputs.is_cuda and train_ops.train_backend() == "hip":
+            if inputs.is_cuda and train_ops.bf16_activations():
                 inputs = inputs.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             return self.decoder(self.encoder(inputs))
         eng = self._engine_for(inputs, _engine.SingleEngine)
@@ -212,7 +212,7 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
             raise W2CError("MO_flag=False is not supported (see eval path)")
         B, N = inputs.shape[0], self.agent_num
         unified = torch.cat(self.divide_inputs(inputs), 0)
-        if inputs.is_cuda and train_ops.train_backend() == "hip":
+        if inputs.is_cuda and train_ops.bf16_activations():
             unified = unified.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)   # bf16 NHWC activations
         feat_maps = self.u_encoder(unified).float()
         val_mat = torch.stack([feat_maps[B * i:B * (i + 1)] for i in range(N)], 1)

@@ -31,13 +31,19 @@ _backend = os.environ.get("W2C_TRAIN_BACKEND", "hip")
 
 def set_train_backend(name):
     global _backend
-    if name not in ("hip", "stock"):
-        raise ValueError("train backend: 'hip' or 'stock'")
+    if name not in ("hip", "stock", "stock_bf16"):
+        raise ValueError("train backend: 'hip', 'stock' (f32 stock ops) or 'stock_bf16' (stock ops on the hip backend's bf16 "
+                         "activation flow: the like-for-like gradient oracle)")
     _backend = name
 
 
 def train_backend():
     return _backend
+
+
+def bf16_activations():
+    """do the models' train paths feed bf16 NHWC activations?"""
+    return _backend in ("hip", "stock_bf16")
 
 
 def _nhwc_bf16(x):
@@ -67,10 +73,14 @@ class _Conv2dHipFn(torch.autograd.Function):
         dev = xh.device
         ones = torch.ones(cout, device=dev)
         shift = bias.detach().float() if bias is not None else torch.zeros(cout, device=dev)
-        y = ops.conv_igemm(xh, 0, cin, _pack_fwd(weight), cout, k, stride, 1, ones, shift, relu=False)
+        M, H, W, _ = xh.shape
+        Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        # the result is allocated as a logical-NCHW channels_last tensor and the kernel writes its NHWC view: the Function
+        # must not return a view it created (a following in-place ReLU would be refused by autograd)
+        y = torch.empty((M, cout, Ho, Wo), dtype=BF16, device=dev, memory_format=torch.channels_last)
+        ops.conv_igemm(xh, 0, cin, _pack_fwd(weight), cout, k, stride, 1, ones, shift, relu=False, out=y.permute(0, 2, 3, 1))
         ctx.save_for_backward(xh, weight)
         ctx.stride, ctx.has_bias, ctx.in_dtype = stride, bias is not None, x.dtype
-        y = y.permute(0, 3, 1, 2)
         return y if x.dtype == BF16 else y.to(x.dtype)        # bf16 in -> bf16 out (the models' train path); else the caller's dtype
 
     @staticmethod
@@ -83,9 +93,9 @@ class _Conv2dHipFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             src = gyh if ctx.stride == 1 else ops.zero_insert2(gyh, H, W)
-            dxh = ops.conv_igemm(src, 0, cout, _pack_dgrad(weight), cin, k, 1, 1, torch.ones(cin, device=dev),
-                                 torch.zeros(cin, device=dev), relu=False)
-            dx = dxh.permute(0, 3, 1, 2)
+            dx = torch.empty((M, cin, H, W), dtype=BF16, device=dev, memory_format=torch.channels_last)
+            ops.conv_igemm(src, 0, cout, _pack_dgrad(weight), cin, k, 1, 1, torch.ones(cin, device=dev),
+                           torch.zeros(cin, device=dev), relu=False, out=dx.permute(0, 2, 3, 1))
             if dx.dtype != ctx.in_dtype:
                 dx = dx.to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
