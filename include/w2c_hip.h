@@ -254,6 +254,10 @@ int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, 
 int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                             float* out, w2c_stream_t stream);
 
+/* Adjoint of K9 for the training backward: gout f32 NCHW [M, n_classes, 32h, 32w] ->
+ * glow f32 NCHW [M, n_classes, h, w] = d loss / d (the low-resolution logits), same source-index rule; deterministic. */
+int w2c_upsample_bilinear32_backward(const float* gout, int M, int h, int w, int n_classes, float* glow, w2c_stream_t stream);
+
 /* ---- SURVEY 8f row 4 (output side): K9 fused with the evaluator's class argmax (trainer.py:804
  * `outputs.data.max(1)[1]`): labels u8 [M, 32h, 32w] = argmax over classes of the bilinear x32 upsample of `low`
  * (identical arithmetic to w2c_upsample_bilinear32, lowest index on ties); the f32 logits are never written. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "w2c_fuse_values": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample32_argmax": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "w2c_upsample_bilinear32_backward": [_vp, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample32_argmax_confusion": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "w2c_confusion_matrix": [_vp, _i, _vp, _ll, _i, _vp, _vp],
     "w2c_nchw_f32_to_nhwc_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp],

@@ -169,6 +169,52 @@ __global__ __launch_bounds__(256) void confusion_kernel(const void* __restrict__
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
+// Adjoint of upsample32_kernel (training backward): glow[m][c][y][x] = sum over the output pixels whose
+// bilinear footprint touches low pixel (y, x) of wy * wx * gout[m][c][oy][ox], with the forward's exact source-index rule.
+// Workgroup = (low row y, class c, image m): the <= 64 output rows that touch row y are reduced along y first (coalesced row
+// reads, each thread owns columns), the W partial sums go through LDS, then every low column sums its <= 64 output columns.
+// Deterministic (no atomics).  Reads each output row at most twice.
+__device__ __forceinline__ float up32_weight(int o, int l, int n) {        // weight of low index l in output index o (n low pixels)
+    float s = (o + 0.5f) * 0.03125f - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    const int i0 = (int)s;
+    const int i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    const float l1 = s - (float)i0;
+    return (i0 == l ? 1.f - l1 : 0.f) + (i1 == l ? l1 : 0.f);
+}
+__global__ __launch_bounds__(256) void upsample32_backward_kernel(const float* __restrict__ gout, int h, int w, int ncls,
+                                                                  float* __restrict__ glow) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* t = reinterpret_cast<float*>(smem);         // [W]
+    const int H = h * 32, W = w * 32;
+    const int y = blockIdx.x, c = blockIdx.y, m = blockIdx.z;
+    const float* g = gout + ((size_t)m * ncls + c) * H * W;
+    const int o_lo = max(0, 32 * y - 16), o_hi = min(H, 32 * y + 48);
+    for (int ox = threadIdx.x; ox < W; ox += 256) {
+        float acc = 0.f;
+        for (int oy = o_lo; oy < o_hi; ++oy) acc = __builtin_fmaf(up32_weight(oy, y, h), g[(size_t)oy * W + ox], acc);
+        t[ox] = acc;
+    }
+    __syncthreads();
+    // low column x: output columns [32x-16, 32x+48); 256 threads = w columns x (256/w) partial sums, reduced through LDS
+    const int per = 256 / w;                            // threads per low column (w <= 32 -> >= 8)
+    const int x = threadIdx.x / per, part = threadIdx.x - x * per;
+    float acc = 0.f;
+    if (x < w) {
+        const int c_lo = max(0, 32 * x - 16), c_hi = min(W, 32 * x + 48);
+        for (int ox = c_lo + part; ox < c_hi; ox += per) acc = __builtin_fmaf(up32_weight(ox, x, w), t[ox], acc);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + W;   // [256]
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (x < w && part == 0) {
+        float s2 = 0.f;
+        for (int k = 0; k < per; ++k) s2 += red[x * per + k];
+        glow[(((size_t)m * ncls + c) * h + y) * w + x] = s2;
+    }
+}
+
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int M, int C, int HW,
                                                            uint16_t* __restrict__ y, int ycs) {
     const size_t total = (size_t)M * HW * C;
@@ -207,6 +253,17 @@ extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, in
     if ((size_t)h * w * 4 > 64 * 1024) return W2C_E_ARG;
     hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), (size_t)h * w * 4,
                        reinterpret_cast<hipStream_t>(stream), low, h, w, low_cstride, n_classes, out);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_upsample_bilinear32_backward(const float* gout, int M, int h, int w, int n_classes, float* glow,
+                                               w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!gout || !glow || M <= 0 || h <= 0 || w <= 0 || w > 256 || n_classes <= 0) return W2C_E_ARG;
+    const size_t lds = ((size_t)w * 32 + 256) * 4;
+    if (lds > 64 * 1024) return W2C_E_ARG;
+    hipLaunchKernelGGL(upsample32_backward_kernel, dim3(h, n_classes, M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       gout, h, w, n_classes, glow);
     return w2c_launch_status();
 }
 

@@ -18,7 +18,7 @@ ResNet-18 key names: third-party pretrainedmodels -> torchvision resnet18.
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..train_ops import Conv2dHip
+from ..train_ops import Conv2dHip, upsample32
 
 
 class BasicBlock(nn.Module):
@@ -102,8 +102,7 @@ class simple_decoder(nn.Module):
                                   Conv2dHip(256, n_classes, kernel_size=3, padding=1))
 
     def forward(self, x):
-        y = self.pred(x).float()                    # (bf16 under the HIP training backend; the upsample and the loss are f32)
-        return F.interpolate(y, size=(x.shape[2] * 32, x.shape[3] * 32), mode="bilinear", align_corners=False)
+        return upsample32(self.pred(x))             # (y is bf16 under the HIP training backend; the upsample and the loss are f32)
 
 
 def _decoder_by_name(name):

@@ -538,6 +538,19 @@ def upsample_bilinear32(low, n_classes, out=None):
     return out
 
 
+def upsample_bilinear32_backward(gout):
+    """gout f32 NCHW [M,C,32h,32w] -> f32 NCHW [M,C,h,w]: the adjoint of upsample_bilinear32."""
+    dev = _need_gpu(gout)
+    M, C, H, W = gout.shape
+    if gout.dtype != torch.float32 or H % 32 or W % 32:
+        raise W2CError("upsample backward: f32 [M,C,32h,32w] expected")
+    glow = torch.empty((M, C, H // 32, W // 32), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_upsample_bilinear32_backward(_p(gout), M, H // 32, W // 32, C, _p(glow), _stream(dev)),
+              "w2c_upsample_bilinear32_backward")
+    return glow
+
+
 def upsample32_argmax(low, n_classes):
     """low f32 NHWC [M,h,w,lcs] -> u8 labels [M,32h,32w] = argmax_c of the bilinear x32 upsample."""
     dev = _need_gpu(low)

@@ -95,6 +95,28 @@ def test_zero_insert2_places_dy_on_the_even_grid():
         assert torch.equal(u, ref)
 
 
+@pytest.mark.parametrize("M,C,h,w", [(2, 11, 4, 4), (3, 11, 16, 16), (1, 5, 8, 32), (2, 3, 1, 1)])
+def test_upsample32_backward_is_the_adjoint_of_the_forward(M, C, h, w):
+    """w2c_upsample_bilinear32_backward vs autograd of F.interpolate (f64), and <up(a), b> == <a, up^T(b)>."""
+    from multiagentperception_amd import ops, train_ops
+    gen = torch.Generator().manual_seed(M + C + h + w)
+    g = torch.randn(M, C, 32 * h, 32 * w, generator=gen)
+    y = torch.randn(M, C, h, w, generator=gen, dtype=torch.float64, requires_grad=True)
+    F.interpolate(y, size=(32 * h, 32 * w), mode="bilinear", align_corners=False).backward(g.double())
+    got = ops.upsample_bilinear32_backward(g.to(_dev()))
+    np.testing.assert_allclose(got.cpu().numpy(), y.grad.float().numpy(), atol=2e-4, rtol=2e-5)
+    again = ops.upsample_bilinear32_backward(g.to(_dev()))
+    assert torch.equal(got, again)
+    # through the autograd Function the decoder uses in train mode
+    train_ops.set_train_backend("hip")
+    yd = y.detach().float().to(_dev()).requires_grad_(True)
+    out = train_ops.upsample32(yd)
+    ref = F.interpolate(y.detach().float(), size=(32 * h, 32 * w), mode="bilinear", align_corners=False)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), atol=1e-6, rtol=1e-6)
+    out.backward(g.to(_dev()))
+    np.testing.assert_allclose(yd.grad.cpu().numpy(), y.grad.float().numpy(), atol=2e-4, rtol=2e-5)
+
+
 def _cfg(arch, n, size, query=True):
     return {"model": dict(arch=arch, agent_num=n, shared_img_encoder="unified", attention="general", sparse=False, query=query,
                           query_size=32, key_size=1024, enc_backbone="resnet_encoder", dec_backbone="simple_decoder",
