@@ -183,11 +183,14 @@ extern "C" long long w2c_conv_wgrad_workspace_bytes(int M, int H, int W, int Cin
     const long rows = (long)M * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
     const long nblocks = (rows + 63) / 64;
     const long tiles = (long)(Cout / 64) * (Cin / 64) * groups;
-    // pixel segments: enough workgroups to fill the chip (~512), but every workgroup must amortise its 64x64x9 f32 partial
-    // tile (147 KB written, then re-read by the reduction) over >= 32 pixel blocks.  (First version: 1536 workgroups whatever
-    // the layer -> 226 MB of partials per layer4 / layer1 conv and a reduction that cost twice the MFMA kernel.)
-    long nseg = (512 + tiles - 1) / tiles;
-    if (nseg > nblocks / 32) nseg = nblocks / 32;
+    // pixel segments: enough workgroups to fill the chip (~768), but every workgroup must amortise its 64x64x9 f32 partial
+    // tile (147 KB written, then re-read by the reduction) over >= 8 pixel blocks, and a conv's partials stay <= 64 MB.
+    // (First version: 1536 workgroups whatever the layer -> 226 MB of partials per layer4 / layer1 conv and a reduction that
+    // cost twice the MFMA kernel; second: >= 32 blocks per workgroup -> ~160 workgroups, 0.6 per CU, 122 us per conv.)
+    long nseg = (768 + tiles - 1) / tiles;
+    if (nseg > nblocks / 8) nseg = nblocks / 8;
+    const long per_seg = (long)groups * Cout * ksize * ksize * Cin * 4;
+    if (nseg * per_seg > (64L << 20)) nseg = (64L << 20) / per_seg;      // <= 64 MB of partials per conv
     if (nseg < 1) nseg = 1;
     return nseg * (long long)groups * Cout * ksize * ksize * Cin * 4;
 }

@@ -4,9 +4,10 @@ the HIP engine.
 
 Dispatch rule (documented in DESIGN.md): ``module.eval()`` -> the HIP path, always -- it raises
 if the input is not on an MI355X or libw2c_hip.so is missing; there is no CPU/PyTorch fallback
-for it.  ``module.train()`` -> the train-mode path needs batch-statistics BatchNorm and autograd
-(out of the accelerated scope) and runs on stock PyTorch-ROCm ops
-over the same parameters.  Note the reference's ``training`` *argument* is only a return-shape
+for it.  ``module.train()`` -> the reference's layer graph under autograd with the 3x3 / 1x1
+convolutions (forward, dX, dW) and the decoder upsample on the HIP kernels (train_ops.py;
+SURVEY.md section 8f row 3, stage 1); batch-statistics BatchNorm, ReLU, pooling, heads and
+attention are stock PyTorch-ROCm ops in the same graph.  Note the reference's ``training`` *argument* is only a return-shape
 flag (validation calls training=True under eval(), trainer.py:692,713); it never selects the path.
 """
 import os
