@@ -176,6 +176,24 @@ int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_c
                         float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream);
 int w2c_zero_insert2_bf16(const uint16_t* dy, int M, int Ho, int Wo, int C, uint16_t* u, int H, int W, w2c_stream_t stream);
 
+/* ---- SURVEY 8f rank 3, stage 2: train-mode BatchNorm2d (batch statistics over all P = M*H*W pixels of the
+ * agent-concatenated batch, agent.py:1108-1111) fused with the residual add and ReLU that follow it in
+ * conv2DBatchNormRelu (models/utils.py:118-120) and the third-party BasicBlock.  x, y, residual, dy, dx : dense bf16 NHWC
+ * [P][C] (C multiple of 8, <= 2048).  Forward: mean/var over P, running stats updated in place with `momentum` (unbiased
+ * var, as nn.BatchNorm2d; pass NULL to skip), y = act(gamma*(x-mean)*rstd + beta (+ residual)); saves mean, rstd [C].
+ * Backward: dyr = dy*[y>0] (y_or_null = the forward's output when relu was applied), dbeta = sum dyr, dgamma = sum dyr*xhat,
+ * dx = gamma*rstd*(dyr - dbeta/P - xhat*dgamma/P), d_residual = dyr (dres_or_null).  Deterministic two-level reductions;
+ * `workspace` >= w2c_bn_workspace_bytes(P, C); ab / k123: [2][C] / [3][C] f32 scratch. */
+long long w2c_bn_workspace_bytes(long long P, int C);
+int w2c_bn_train_forward(const uint16_t* x, long long P, int C, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps,
+                         const uint16_t* residual, int relu, uint16_t* y,
+                         float* mean, float* rstd, float* ab, void* workspace, long long workspace_bytes, w2c_stream_t stream);
+int w2c_bn_train_backward(const uint16_t* dy, const uint16_t* y_or_null, const uint16_t* x, long long P, int C,
+                          const float* gamma, const float* mean, const float* rstd,
+                          uint16_t* dx, uint16_t* dres_or_null, float* dgamma, float* dbeta,
+                          float* k123, void* workspace, long long workspace_bytes, w2c_stream_t stream);
+
 /* Unit-test probes of the two fp8 primitives: c[32][32] f32 = a[32][64] . b[32][64]^T (e4m3, one MX-scaled MFMA with
  * unit block scales); y[n] = e4m3(x[n]) as the conv epilogues pack it (round to nearest even, saturating). */
 int w2c_debug_mx_mfma(const uint8_t* a, const uint8_t* b, float* c, w2c_stream_t stream);

@@ -39,6 +39,9 @@ SIGNATURES = {
     "w2c_conv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_conv_wgrad_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _ll, _vp],
     "w2c_zero_insert2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "w2c_bn_workspace_bytes": [_ll, _i],
+    "w2c_bn_train_forward": [_vp, _ll, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
+    "w2c_bn_train_backward": [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
     "w2c_debug_mx_mfma": [_vp, _vp, _vp, _vp],
     "w2c_debug_fp8_pack": [_vp, _vp, _i, _vp],
     "w2c_linear_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
@@ -84,7 +87,7 @@ def lib():
                 raise W2CError("libw2c_hip.so does not export %s (stale build?)" % name)
             fn.argtypes = argtypes
             fn.restype = (_c.c_char_p if name in ("w2c_status_string", "w2c_last_error_string") else
-                          _c.c_longlong if name in ("w2c_conv_splitk_workspace_bytes", "w2c_conv_wgrad_workspace_bytes") else _i)
+                          _c.c_longlong if name in ("w2c_conv_splitk_workspace_bytes", "w2c_conv_wgrad_workspace_bytes", "w2c_bn_workspace_bytes") else _i)
         _lib = handle
     return _lib
 

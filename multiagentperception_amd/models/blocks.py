@@ -18,7 +18,7 @@ ResNet-18 key names: third-party pretrainedmodels -> torchvision resnet18.
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..train_ops import Conv2dHip, upsample32
+from ..train_ops import Conv2dHip, bn_act, upsample32
 
 
 class BasicBlock(nn.Module):
@@ -34,10 +34,10 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(Conv2dHip(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
         self.stride = stride
 
-    def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        return self.relu(self.bn2(self.conv2(y)) + idt)
+    def forward(self, x):                           # train mode only (eval runs on the engine); BN + add + ReLU fused (train_ops.bn_act)
+        idt = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        y = bn_act(self.bn1, self.conv1(x), relu=True)
+        return bn_act(self.bn2, self.conv2(y), relu=True, residual=idt)
 
 
 class ResNet18(nn.Module):
@@ -70,8 +70,11 @@ class resnet_encoder(nn.Module):
         self.backbone_3 = fb.layer3
         self.backbone_4 = fb.layer4
 
-    def forward(self, x):
-        for stage in (self.backbone_0, self.backbone_1, self.backbone_2, self.backbone_3, self.backbone_4):
+    def forward(self, x):                           # backbone.py:72-96: conv1 -> bn1 -> relu -> maxpool -> layer1..4
+        fb = self.feature_backbone
+        x = bn_act(fb.bn1, fb.conv1(x), relu=True)
+        x = fb.maxpool(x)
+        for stage in (fb.layer1, self.backbone_2, self.backbone_3, self.backbone_4):
             x = stage(x)
         return x
 
@@ -84,7 +87,7 @@ class conv2DBatchNormRelu(nn.Module):
             nn.BatchNorm2d(int(n_filters)), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        return self.cbr_unit(x)
+        return bn_act(self.cbr_unit[1], self.cbr_unit[0](x), relu=True)
 
 
 def _encoder_by_name(name):

