@@ -197,7 +197,7 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
         assert pred.dtype == torch.float32 and pred.shape == (b * n, 11, s, s)
         loss = F.cross_entropy(pred, labels, ignore_index=250)               # loss/loss.py:5-18
         loss.backward()
-        res[backend] = (float(loss), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None})
+        res[backend] = (float(loss.detach()), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None})
     train_ops.set_train_backend("hip")
 
     def cosines(name):
