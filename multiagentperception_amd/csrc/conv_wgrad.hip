@@ -25,7 +25,7 @@ struct WgradArgs {
     int Ho, Wo, Cout, ycs;
     int ks, stride, pad;
     int rows;          // M*Ho*Wo
-    int nseg, blocks_per_seg;   // 64-pixel blocks per segment
+    int nseg, blocks_per_seg;   // 128-pixel blocks per segment
     int nct_o, nct_i;  // 64-channel tiles along Cout / Cin
 };
 
@@ -38,11 +38,20 @@ __device__ __forceinline__ void wg_wait_vmcnt() {
 // (The builtin, not inline asm: the compiler then tracks lgkmcnt for the two reads.)
 typedef __attribute__((ext_vector_type(4))) short w2c_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short w2c_s16x8_t;
+// LDS image of a tile: row = pixel (128 B = 64 channels); the four 32-byte windows of row p are stored at window index
+// w ^ (p & 2): the 32 lanes serviced together by a ds_read_b64(_tr) read 4 consecutive pixels x 2 channel halves = 8 pieces of
+// 32 B, which then fall on 8 distinct (row parity, window) slots of the 256-byte bank space -- conflict-free (at pitch 128 B
+// unswizzled, rows p and p+2 share their banks).
+__device__ __forceinline__ int wg_swz(int p) { return p & 2; }
 __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int pix0, int cbase, int lane) {
     const int lhi = lane >> 5, g16 = (lane >> 4) & 1, r = (lane & 15) >> 2, q = lane & 3;
-    const char* a = tile + (pix0 + 8 * lhi + r) * 128 + (cbase + 16 * g16 + 4 * q) * 2;
-    const w2c_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2c_s16x4_t*)(a));
-    const w2c_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2c_s16x4_t*)(a + 512));
+    const int p = pix0 + 8 * lhi + r;
+    const int cb = (cbase + 16 * g16 + 4 * q) * 2;                 // byte offset of this lane's 4 channels inside the row
+    const int w = cb >> 5, in = cb & 31;
+    const char* a0 = tile + p * 128 + ((w ^ wg_swz(p)) << 5) + in;
+    const char* a1 = tile + (p + 4) * 128 + ((w ^ wg_swz(p + 4)) << 5) + in;
+    const w2c_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2c_s16x4_t*)(a0));
+    const w2c_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2c_s16x4_t*)(a1));
     const w2c_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -50,7 +59,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int pix0, int cbas
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BP = 64;                       // pixels per block
+    constexpr int BP = 128;                      // pixels per block (8 MFMA k-steps per tap: one barrier per 256 MFMA cycles per wave)
+    constexpr int NJ = BP / 32;                  // DMA instructions per wave per tile (8 pixel rows each, 4 waves)
     __shared__ __attribute__((aligned(16))) char smem[BP * 128 * 3];      // dY tile | X tile x 2
     char* const Ys = smem;
     char* const Xs = smem + BP * 128;
@@ -80,21 +90,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int b_end = min(nblocks, b_begin + p.blocks_per_seg);
     for (int blk = b_begin; blk < b_end; ++blk) {
         const int p0 = blk * BP;
-        // this lane's two pixel rows of the block (DMA instruction j moves rows (wave + 4j)*8 + lrow)
-        int iy0[2], ix0[2];
-        unsigned ybase[2];
-        int xbase[2];
+        // this lane's NJ pixel rows of the block (DMA instruction j moves rows (wave + 4j)*8 + lrow); LDS chunk position lpos
+        // holds the SOURCE chunk ((lpos>>1) ^ swz(row)) : lpos&1 (the swizzle is applied on the source side, see wg_swz)
+        int iy0[NJ], ix0[NJ];
+        unsigned ybase[NJ];
+        int xbase[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pr = p0 + (wave + 4 * j) * 8 + lrow;
+        for (int j = 0; j < NJ; ++j) {
+            const int rloc = (wave + 4 * j) * 8 + lrow;
+            const int pr = p0 + rloc;
+            const int src16 = ((((lpos >> 1) ^ wg_swz(rloc)) << 1) | (lpos & 1)) * 16;
             if (pr < p.rows) {
                 const int hw = p.Ho * p.Wo;
                 const int m = pr / hw, rem = pr - m * hw;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 iy0[j] = oy * p.stride - p.pad;
                 ix0[j] = ox * p.stride - p.pad;
-                ybase[j] = (unsigned)((size_t)pr * p.ycs * 2 + lpos * 16);
-                xbase[j] = (int)((((long)m * p.H + iy0[j]) * p.W + ix0[j]) * p.xcs * 2 + lpos * 16);
+                ybase[j] = (unsigned)((size_t)pr * p.ycs * 2 + src16);
+                xbase[j] = (int)((((long)m * p.H + iy0[j]) * p.W + ix0[j]) * p.xcs * 2 + src16);
             } else {
                 iy0[j] = -100000; ix0[j] = 0; ybase[j] = 0x80000000u; xbase[j] = 0;
             }
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap - 3 * (tap / 3);
             const int tap_off = (ky * p.W + kx) * p.xcs * 2;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int iy = iy0[j] + ky, ix = ix0[j] + kx;
                 const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
                 const unsigned vo = ok ? (unsigned)(xbase[j] + tap_off) : 0x80000000u;
@@ -112,10 +125,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         };
         __syncthreads();                                   // previous block's tiles are no longer read
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, W2C_LPTR(Ys + (wave + 4 * j) * 1024), 16, ybase[j], 0, 0, 0);
         stage_x(0, 0);
-        bf16x8_t ya[4];
+        bf16x8_t ya[BP / 16];
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             wg_wait_vmcnt<0>();
@@ -123,11 +136,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             if (tap + 1 < TAPS) stage_x(tap + 1, (tap + 1) & 1);
             if (tap == 0) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) ya[kk] = tr_frag(Ys, kk * 16, wm * 32, lane);
+                for (int kk = 0; kk < BP / 16; ++kk) ya[kk] = tr_frag(Ys, kk * 16, wm * 32, lane);
             }
             const char* xt = Xs + (tap & 1) * (BP * 128);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < BP / 16; ++kk) {
                 const bf16x8_t xb = tr_frag(xt, kk * 16, wn * 32, lane);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[kk], xb, acc[tap], 0, 0, 0);
             }
@@ -181,14 +194,14 @@ extern "C" long long w2c_conv_wgrad_workspace_bytes(int M, int H, int W, int Cin
     if (!((ksize == 3) || (ksize == 1)) || !((stride == 1) || (stride == 2))) return -1;
     const int pad = ksize == 3 ? 1 : 0;
     const long rows = (long)M * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
-    const long nblocks = (rows + 63) / 64;
+    const long nblocks = (rows + 127) / 128;
     const long tiles = (long)(Cout / 64) * (Cin / 64) * groups;
     // pixel segments: enough workgroups to fill the chip (~768), but every workgroup must amortise its 64x64x9 f32 partial
     // tile (147 KB written, then re-read by the reduction) over >= 8 pixel blocks, and a conv's partials stay <= 64 MB.
     // (First version: 1536 workgroups whatever the layer -> 226 MB of partials per layer4 / layer1 conv and a reduction that
     // cost twice the MFMA kernel; second: >= 32 blocks per workgroup -> ~160 workgroups, 0.6 per CU, 122 us per conv.)
     long nseg = (768 + tiles - 1) / tiles;
-    if (nseg > nblocks / 8) nseg = nblocks / 8;
+    if (nseg > nblocks / 4) nseg = nblocks / 4;
     const long per_seg = (long)groups * Cout * ksize * ksize * Cin * 4;
     if (nseg * per_seg > (64L << 20)) nseg = (64L << 20) / per_seg;      // <= 64 MB of partials per conv
     if (nseg < 1) nseg = 1;
@@ -215,7 +228,7 @@ extern "C" int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int C
     a.rows = M * a.Ho * a.Wo;
     const long per = (long)groups * Cout * ksize * ksize * Cin * 4;
     a.nseg = (int)(need / per);
-    const int nblocks = (a.rows + 63) / 64;
+    const int nblocks = (a.rows + 127) / 128;
     a.blocks_per_seg = (nblocks + a.nseg - 1) / a.nseg;
     a.nct_o = Cout / 64; a.nct_i = Cin / 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
