@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="force the bf16 trunk (cfg5 defaults to fp8)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: debugging only (several ranks on one GPU; RCCL refuses that)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="N=1 only: run the multi-rank code path (3 graph segments + in-place RCCL all-gathers) with one rank")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     preset = dict(PRESETS[args.config])
@@ -249,6 +251,10 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
+    if world == 1 and args.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -281,6 +287,8 @@ def main():
         frames = np.ascontiguousarray(frames_all[:, 3 * rank * n_loc:3 * (rank + 1) * n_loc])
     x = torch.from_numpy(frames).to(dev)
     fwd = AgentParallelForward(model)
+    if args.force_sharded:
+        fwd.force_sharded = True
 
     def step():
         return fwd(x, inference=args.mode)
@@ -349,7 +357,8 @@ def main():
                   config=dict(workload=workload, preset=args.config, agents_total=N, agents_per_gpu=n_loc, global_batch=B,
                               frames_per_s=round(B * args.steps / elapsed, 2),
                               parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
-                              launch=("hip-graph replay" if world == 1 else "3 hip-graph segments + eager collectives")
+                              launch=("hip-graph replay" if (world == 1 and not args.force_sharded) else
+                                      "3 hip-graph segments + eager collectives")
                               if model.use_hip_graph else "eager"),
                   roofline=roofline)
 
@@ -429,7 +438,7 @@ def main():
         result["speedup_vs_cpu"] = round(value / base["value"], 1)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -16,6 +16,8 @@ asynchronously as soon as the trunk's squeezer output exists so it overlaps the 
 ``exchange_*`` are backend-agnostic (tested with gloo on CPU, world_size 2); the compute around
 them is the HIP engine and needs a GPU.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -181,6 +183,10 @@ class AgentParallelForward:
         self.q_lo, self.n_loc = shard_agents(model.agent_num, self.world, self.rank)
         self._engine_cls = _engine.CommEngine
         self.last_exchange = None
+        # force_sharded: take the multi-rank code path (segment graphs + in-place RCCL all-gathers) even with ONE rank -- the
+        # only way to execute the RCCL calls and their interplay with graph capture on a single-GPU box (tests, bench
+        # --force-sharded); results equal forward_local's bit for bit
+        self.force_sharded = os.environ.get("W2C_FORCE_SHARDED", "0") == "1"
 
     def _state(self, eng, x):
         cache = eng.__dict__.setdefault("_shard_states", {})          # dies with the engine (load_state_dict / .to() / train())
@@ -203,7 +209,7 @@ class AgentParallelForward:
         use_graph = bool(getattr(model, "use_hip_graph", False))
         with torch.no_grad():
             x = inputs_local.contiguous().float()
-            if self.world == 1:
+            if self.world == 1 and not (self.force_sharded and dist.is_initialized()):
                 return eng.forward_local(x, B, N, inference, use_graph=use_graph)
             st = self.encode_local(eng, x, use_graph)
             if inference != "softmax":
@@ -236,7 +242,7 @@ class AgentParallelForward:
         from . import ops
         B, N = st.B, st.N
         st.run("B", lambda: eng.policy_tail(st.pol, ch_off=0, outs=(st.k_slot, st.q_loc)), use_graph)
-        k_work = _gather_inplace(st.k_all, self.rank, self.n_loc * B, self.group) if self.world > 1 else None
+        k_work = _gather_inplace(st.k_all, self.rank, self.n_loc * B, self.group) if dist.is_initialized() else None
         q_all, q_work = (exchange_start(st.q_loc, self.group) if st.q_loc is not None else (None, None))
         exchange_wait(k_work)
         exchange_wait(q_work)

@@ -98,3 +98,22 @@ def test_bench_self_launches_its_ranks_and_reports_comm(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["agents_total"] == 8
     assert d["config"]["agents_per_gpu"] == 4 and d["comm"]["ranks"] == 2 and d["comm"]["us_per_step_unoverlapped"] > 0
     assert d["value"] > 0 and d["roofline"]["launches_per_step"] == 27
+
+
+def test_single_rank_rccl_executes_the_sharded_code_path():
+    """The multi-rank path -- RCCL process group, in-place all_gather_into_tensor on the buffers the kernels wrote, async work
+    handles, three captured graph segments with RCCL's watchdog thread alive -- executed with ONE rank (RCCL refuses two ranks on
+    one GPU; an 8-GPU node is only available to the driver).  Must print the same kind of line and, being bit-identical code,
+    parity must hold."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-sharded", "--batch", "2", "--size", "128",
+                        "--steps", "5", "--warmup", "2", "--no-pmc"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and "segments" in d["config"]["launch"]
+    assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
