@@ -436,10 +436,16 @@ def main():
             prob_max_abs=float((out[1].cpu() - ref_out[1]).abs().max()),
             miou_hip_vs_oracle_argmax=orc.mean_iou(orc.confusion_matrix(rl, hl)))
         result["speedup_vs_cpu"] = round(value / base["value"], 1)
-    if rank == 0:
-        print(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL writes a version banner to the C stdout of rank 0; flush it first so that the JSON line is the LAST line on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

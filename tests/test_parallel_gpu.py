@@ -114,6 +114,8 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
                         "--steps", "5", "--warmup", "2", "--no-pmc"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    out_lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert out_lines[-1].startswith("{"), out_lines[-3:]                     # the JSON line is the last line (RCCL's banner precedes it)
+    d = json.loads(out_lines[-1])
     assert d["n_gpus"] == 1 and "segments" in d["config"]["launch"]
     assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
