@@ -209,6 +209,32 @@ def _apply_precision(model, args):
     return "bf16"
 
 
+_saved_stdout_fd = None
+
+
+def _stdout_to_stderr():
+    """point fd 1 at stderr until the final print (C-level writers such as RCCL's banner included)"""
+    global _saved_stdout_fd
+    sys.stdout.flush()
+    _saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _restore_stdout():
+    global _saved_stdout_fd
+    if _saved_stdout_fd is None:
+        return
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    os.dup2(_saved_stdout_fd, 1)
+    os.close(_saved_stdout_fd)
+    _saved_stdout_fd = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,6 +265,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    _stdout_to_stderr()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -438,12 +465,9 @@ def main():
         result["speedup_vs_cpu"] = round(value / base["value"], 1)
     if dist.is_initialized():
         dist.destroy_process_group()
-    # RCCL writes a version banner to the C stdout of rank 0; flush it first so that the JSON line is the LAST line on stdout
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    # stdout carries the ONE JSON line and nothing else: everything the libraries wrote to fd 1 meanwhile (RCCL prints a version
+    # banner on rank 0's C stdout) went to stderr -- see _stdout_to_stderr()
+    _restore_stdout()
     if rank == 0:
         print(json.dumps(result), flush=True)
 

@@ -115,7 +115,7 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
                        timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     out_lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
-    assert out_lines[-1].startswith("{"), out_lines[-3:]                     # the JSON line is the last line (RCCL's banner precedes it)
-    d = json.loads(out_lines[-1])
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines[-3:]   # ONE JSON line (RCCL's banner goes to stderr)
+    d = json.loads(out_lines[0])
     assert d["n_gpus"] == 1 and "segments" in d["config"]["launch"]
     assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
