@@ -232,6 +232,14 @@ class AgentParallelForward:
         the policy-encoder map in st.pol.  Returns the shard state."""
         st = self._state(eng, x)
         eng.trunk.stem(x, self.n_loc, out=st.s0)
+        if eng.trunk.n8 and eng.trunk.fp8 is None:
+            # fp8 trunk: every rank must quantise with the SAME activation scales, or a shard would round differently from the
+            # unsharded batch -- the calibration pass's amax vector is all-reduced (MAX) once, before anything is captured
+            def _max_over_ranks(amax):
+                if dist.is_initialized() and self.world > 1:
+                    dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
+                return amax
+            eng.trunk.calibrate(st.s0, reduce_amax=_max_over_ranks)
         st.run("A", lambda: tuple(eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol])), use_graph)
         return st
 

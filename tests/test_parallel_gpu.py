@@ -27,7 +27,7 @@ def _cfg(n, size):
     return {"model": model, "data": {"img_rows": size, "img_cols": size}}
 
 
-def _worker(rank, world, port, N, B, S, seed, mode, out_dir, graph=False):
+def _worker(rank, world, port, N, B, S, seed, mode, out_dir, graph=False, precision="bf16"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,11 +37,12 @@ def _worker(rank, world, port, N, B, S, seed, mode, out_dir, graph=False):
     model = get_model(_cfg(N, S), 11)
     filler.apply_to_module(model)
     model = model.to("cuda:0").eval()
+    model.set_trunk_precision(precision)
     q_lo, n_loc = shard_agents(N, world, rank)
     x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
     fwd = AgentParallelForward(model)
     model.use_hip_graph = graph
-    if graph:        # capture on OTHER frames first, so the checked call is a pure replay through the static buffers
+    if graph and precision == "bf16":   # capture on OTHER frames first, so the checked call is a pure replay through the static buffers
         other = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed + 1))
         fwd(other[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
     pred, prob, action, nnz = fwd(x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
@@ -119,3 +120,23 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
     d = json.loads(out_lines[0])
     assert d["n_gpus"] == 1 and "segments" in d["config"]["launch"]
     assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_fp8_trunk_quantises_alike_on_every_rank(tmp_path, graph):
+    """fp8 value encoder, sharded: the calibration amax is all-reduced (MAX) over the ranks, so every rank uses the scales the
+    unsharded batch would have calibrated (amax of a union = max of the amaxes) and the shard is bit-identical again."""
+    from oracle import filler
+    from ptsemseg.models import get_model
+    world, N, B, S, seed = 2, 4, 2, 128, 99
+    mp.spawn(_worker, args=(world, _free_port(), N, B, S, seed, "softmax", str(tmp_path), graph, "fp8"), nprocs=world, join=True)
+    model = get_model(_cfg(N, S), 11)
+    filler.apply_to_module(model)
+    model = model.to("cuda:0").eval().set_trunk_precision("fp8")
+    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed)).cuda()
+    pred, prob, action, _ = model(x, training=False, MO_flag=True, inference="softmax")
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        lo, n = d["q_lo"], d["n_loc"]
+        assert torch.equal(d["prob"], prob.cpu()[:, :, lo:lo + n])
+        assert torch.equal(d["pred"], pred.cpu()[lo * B:(lo + n) * B])
