@@ -194,6 +194,13 @@ int w2c_bn_train_backward(const uint16_t* dy, const uint16_t* y_or_null, const u
                           uint16_t* dx, uint16_t* dres_or_null, float* dgamma, float* dbeta,
                           float* k123, void* workspace, long long workspace_bytes, w2c_stream_t stream);
 
+/* maxpool 3x3 s2 p1 for the training path (backbone.py:66): forward also records, per output element, the tap index 3*ky+kx of
+ * the first maximum (idx u8 [M,H/2,W/2,C]); backward gathers dy over the <= 4 windows that selected each input element.
+ * x, dx : bf16 NHWC [M,H,W,C]; y, dy : [M,H/2,W/2,C]; H, W even; C multiple of 8. */
+int w2c_maxpool3x3s2_train_forward(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, uint8_t* idx, w2c_stream_t stream);
+int w2c_maxpool3x3s2_train_backward(const uint16_t* dy, const uint8_t* idx, int M, int H, int W, int C, uint16_t* dx,
+                                    w2c_stream_t stream);
+
 /* Unit-test probes of the two fp8 primitives: c[32][32] f32 = a[32][64] . b[32][64]^T (e4m3, one MX-scaled MFMA with
  * unit block scales); y[n] = e4m3(x[n]) as the conv epilogues pack it (round to nearest even, saturating). */
 int w2c_debug_mx_mfma(const uint8_t* a, const uint8_t* b, float* c, w2c_stream_t stream);

@@ -258,3 +258,97 @@ extern "C" int w2c_bn_train_backward(const uint16_t* dy, const uint16_t* y_or_nu
                        (long)P, C, dx, dres_or_null);
     return w2c_launch_status();
 }
+
+// ---- maxpool 3x3 / stride 2 / pad 1 for the training path (backbone.py:66 via the third-party resnet18's maxpool) ----
+// forward: y and, per output element, the tap index 3*ky+kx of the FIRST maximum in scan order (what nn.MaxPool2d's backward
+// routes the gradient to); backward: every input element sums dy over the <= 4 windows that selected it (a gather: no atomics).
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool_train_fwd_kernel(const uint16_t* __restrict__ x, int M, int H, int W, int C,
+                                                                uint16_t* __restrict__ y, uint8_t* __restrict__ idx) {
+    const int Ho = H >> 1, Wo = W >> 1, cg = C >> 3;
+    const long total = (long)M * Ho * Wo * cg;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const int g = (int)(id % cg);
+        long t = id / cg;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int m = (int)(t / Ho);
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(x + (((size_t)m * H + iy) * W + ix) * C + g * 8), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (v[e] > best[e] || (bi[e] == 0 && best[e] == -INFINITY)) { best[e] = v[e]; bi[e] = ky * 3 + kx; }
+                }
+            }
+        *reinterpret_cast<uint4*>(y + id * 8) = pack8(best);
+        uint2 o;
+        o.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        o.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+        *reinterpret_cast<uint2*>(idx + id * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_train_bwd_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, int M, int H,
+                                                                int W, int C, uint16_t* __restrict__ dx) {
+    const int Ho = H >> 1, Wo = W >> 1, cg = C >> 3;
+    const long total = (long)M * H * W * cg;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const int g = (int)(id % cg);
+        long t = id / cg;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const int m = (int)(t / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        // windows (oy, ox) with 2oy-1 <= iy <= 2oy+1: oy = iy/2 (even iy) or {iy/2, iy/2+1} (odd iy); same for x
+        for (int oy = iy >> 1; oy <= ((iy + 1) >> 1); ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - (2 * oy - 1);
+            for (int ox = ix >> 1; ox <= ((ix + 1) >> 1); ++ox) {
+                if (ox >= Wo) continue;
+                const int tap = ky * 3 + (ix - (2 * ox - 1));
+                const size_t o = ((((size_t)m * Ho + oy) * Wo + ox) * cg + g) * 8;
+                const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
+                float gv[8];
+                unpack8(*reinterpret_cast<const uint4*>(dy + o), gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int sel = (int)(((e < 4 ? iv.x : iv.y) >> (8 * (e & 3))) & 0xFF);
+                    acc[e] += sel == tap ? gv[e] : 0.f;
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(dx + id * 8) = pack8(acc);
+    }
+}
+
+}  // namespace
+
+extern "C" int w2c_maxpool3x3s2_train_forward(const uint16_t* x, int M, int H, int W, int C, uint16_t* y, uint8_t* idx, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !y || !idx || M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8)) return W2C_E_ARG;
+    hipLaunchKernelGGL(maxpool_train_fwd_kernel, dim3(ew_grid((long)M * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, M, H, W, C, y, idx);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_maxpool3x3s2_train_backward(const uint16_t* dy, const uint8_t* idx, int M, int H, int W, int C, uint16_t* dx,
+                                               w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!dy || !dx || !idx || M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8)) return W2C_E_ARG;
+    hipLaunchKernelGGL(maxpool_train_bwd_kernel, dim3(ew_grid((long)M * H * W * (C / 8))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dy, idx, M, H, W, C, dx);
+    return w2c_launch_status();
+}

@@ -18,7 +18,7 @@ ResNet-18 key names: third-party pretrainedmodels -> torchvision resnet18.
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..train_ops import Conv2dHip, bn_act, upsample32
+from ..train_ops import Conv2dHip, bn_act, maxpool3x3s2, upsample32
 
 
 class BasicBlock(nn.Module):
@@ -73,7 +73,7 @@ class resnet_encoder(nn.Module):
     def forward(self, x):                           # backbone.py:72-96: conv1 -> bn1 -> relu -> maxpool -> layer1..4
         fb = self.feature_backbone
         x = bn_act(fb.bn1, fb.conv1(x), relu=True)
-        x = fb.maxpool(x)
+        x = maxpool3x3s2(fb.maxpool, x)
         for stage in (fb.layer1, self.backbone_2, self.backbone_3, self.backbone_4):
             x = stage(x)
         return x

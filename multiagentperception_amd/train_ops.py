@@ -192,3 +192,40 @@ def bn_act(bn, x, relu, residual=None):
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """maxpool 3x3 s2 p1 (backbone.py:66) on the HIP kernels: forward records the selected tap, backward gathers."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xh = x.permute(0, 2, 3, 1)
+        M, H, W, C = xh.shape
+        y = torch.empty((M, C, H // 2, W // 2), dtype=BF16, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((M, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            ops.check(ops._native.lib().w2c_maxpool3x3s2_train_forward(xh.data_ptr(), M, H, W, C, y.data_ptr(), idx.data_ptr(),
+                                                                        ops._stream(x.device)), "w2c_maxpool3x3s2_train_forward")
+        ctx.save_for_backward(idx)
+        ctx.shape = (M, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        M, H, W, C = ctx.shape
+        gyh = _nhwc_bf16(gy)
+        dx = torch.empty((M, C, H, W), dtype=BF16, device=gy.device, memory_format=torch.channels_last)
+        with torch.cuda.device(gy.device):
+            ops.check(ops._native.lib().w2c_maxpool3x3s2_train_backward(gyh.data_ptr(), idx.data_ptr(), M, H, W, C, dx.data_ptr(),
+                                                                         ops._stream(gy.device)), "w2c_maxpool3x3s2_train_backward")
+        return dx
+
+
+def maxpool3x3s2(pool, x):
+    """train-mode resnet maxpool: HIP kernels for bf16 channels_last GPU tensors under the "hip" backend, else the module."""
+    if (_backend == "hip" and x.is_cuda and x.dtype == BF16 and x.dim() == 4 and x.shape[1] % 8 == 0 and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and (pool.kernel_size, pool.stride, pool.padding) == (3, 2, 1)):
+        return _MaxPoolFn.apply(x)
+    return pool(x)

@@ -165,6 +165,25 @@ def test_fused_bn_train_forward_backward_match_autograd(M, C, H, W, relu, res):
                                atol=2e-3 * float(ref_bn.bias.grad.abs().max()), rtol=2e-3)
 
 
+@pytest.mark.parametrize("M,C,H,W", [(2, 64, 16, 16), (3, 128, 10, 6), (1, 64, 128, 128)])
+def test_maxpool_train_forward_backward_match_autograd(M, C, H, W):
+    from multiagentperception_amd import train_ops
+    gen = torch.Generator().manual_seed(M + C + H)
+    x = torch.randn(M, C, H, W, generator=gen).to(BF16).float()
+    x[:, :, :4, :4] = 0.0                                            # ties (post-ReLU zeros): first maximum in scan order
+    gy = torch.randn(M, C, H // 2, W // 2, generator=gen).to(BF16).float()
+    xr = x.clone().requires_grad_(True)
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    yr = pool(xr)
+    yr.backward(gy)
+    train_ops.set_train_backend("hip")
+    xd = x.to(_dev()).to(BF16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yd = train_ops.maxpool3x3s2(pool, xd)
+    yd.backward(gy.to(_dev()).to(BF16))
+    assert torch.equal(yd.float().cpu(), yr.detach())
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.numpy(), atol=1e-6, rtol=2 ** -7)   # (sum of <= 4 bf16 rounded once)
+
+
 def _cfg(arch, n, size, query=True):
     return {"model": dict(arch=arch, agent_num=n, shared_img_encoder="unified", attention="general", sparse=False, query=query,
                           query_size=32, key_size=1024, enc_backbone="resnet_encoder", dec_backbone="simple_decoder",
