@@ -29,6 +29,7 @@
 // XORs make each group's 16 (row-in-bank-row, position) pairs distinct => conflict-free
 // (MI355X_MICROARCH.md LDS table).
 #include "w2c_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -93,6 +94,13 @@ __device__ __forceinline__ void store_out8(const ConvArgs& p, const float (&v)[8
 __device__ __forceinline__ void dbg_stamp(const ConvArgs& p, int slot) {
     if (p.dbg && threadIdx.x == 0)
         p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + slot] = wall_clock64();
+}
+
+// Tap order of the stride-2 3x3 convs: grouped by input phase (see conv3x3s2_patch_kernel) -- every kernel that computes a
+// stride-2 3x3 conv walks the taps of a chunk in THIS order, so the halo-patch kernel and the generic kernel stay bit-identical.
+__device__ __forceinline__ void s2_tap(int i, int& ky, int& kx) {
+    ky = (int)((0x002202111ull >> (4 * (8 - i))) & 0xF);    // i: 0..8 -> ky = 0 0 2 2 0 2 1 1 1   (9 nibbles: 64-bit constants)
+    kx = (int)((0x020211021ull >> (4 * (8 - i))) & 0xF);    //             kx = 0 2 0 2 1 1 0 2 1
 }
 
 template <int N>
@@ -213,8 +221,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
     // chunk) -- so that every kernel of this file adds the same MFMA products in the same sequence and the results do
     // not depend on which variant pick_variant() chose (i.e. on the image count: shard == unsharded batch, bit for bit)
     const int ntap = p.ks * p.ks;
+    const bool s2order = p.ks == 3 && p.stride == 2;             // stride-2 3x3: phase-grouped tap order (s2_tap)
     int st_ct = t_begin / ntap;
-    int st_ky = (t_begin - st_ct * ntap) / p.ks, st_kx = (t_begin - st_ct * ntap) % p.ks;
+    int st_tap = t_begin - st_ct * ntap;
+    int st_ky = st_tap / p.ks, st_kx = st_tap % p.ks;
+    if (s2order) s2_tap(st_tap, st_ky, st_kx);
 
     auto stage = [&](int buf) {
         char* As = smem + buf * STAGE_BYTES;
@@ -240,10 +251,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
                                                              st_ct * BK * 2, 0, 0);
             }
         }
-        if (++st_kx == p.ks) {
-            st_kx = 0;
-            if (++st_ky == p.ks) { st_ky = 0; ++st_ct; }
-        }
+        if (++st_tap == ntap) { st_tap = 0; ++st_ct; }
+        if (s2order) s2_tap(st_tap, st_ky, st_kx);
+        else { st_ky = st_tap / p.ks; st_kx = st_tap - st_ky * p.ks; }
     };
 
     f32x16_t acc[MI][NI];
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         pipeline_barrier();                                              // everyone's part landed; tile t-1's buffer is free
         if (t == 0) dbg_stamp(p, 1);
         if (t + STAGES - 1 < KT) stage(wr);
-        compute(rd, DUAL && c_tap == 4);
+        compute(rd, DUAL && c_tap == 8);              // the centre tap (1,1) is the LAST tap of the stride-2 order
         if (DUAL) c_tap = (c_tap == 8) ? 0 : c_tap + 1;
         rd = (rd + 1 == STAGES) ? 0 : rd + 1;
         wr = (wr + 1 == STAGES) ? 0 : wr + 1;
@@ -849,6 +859,320 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 #endif
 }
 
+
+// =====================================================================================================
+// Stride-2 block front on halo patches: conv1 3x3 / s2 / p1 (+ the 1x1 / s2 downsample) of a BasicBlock.
+//
+// A stride-2 3x3 conv is a 2x2 stride-1 conv over the four POLYPHASE components of its input: input row 2oy-1+ky is
+// phase py = (ky != 1) of pixel-block row oy-1 (ky = 0) or oy (ky = 1, 2), same along x.  So per 64-channel chunk the
+// workgroup stages FOUR small patches instead of re-gathering its rows 9 times -- patch(py,px) = the (TH+1) x (TW+1) blocks
+// around the tile, one pixel (2by+py, 2bx+px) each; the per-lane DMA source offsets make the stride-2 gather free -- and
+// every tap reads its A fragments from the patch of its phase at a block shift (dby, dbx) in {0,1}^2:
+//     phase (1,1): taps (0,0) (0,2) (2,0) (2,2)      phase (1,0): (0,1) (2,1)      phase (0,1): (1,0) (1,2)
+//     phase (0,0): tap (1,1)  -- whose pixels (2oy, 2ox) are exactly the 1x1/s2 downsample's: a 10th K-step per chunk
+//                                multiplies the same fragments with the downsample's weight tile into a second accumulator.
+// Activation traffic L2->LDS: 4 x 162 pixels per chunk instead of 9 x 128 rows re-gathered, 9 (10) weight tiles as before;
+// 8 waves (4 x 2, wave tile 32 px x 32 ch), patches double-buffered across phases (every phase has >= 2 steps, so the next
+// patch is issued two steps ahead), 3-deep weight ring, counted vmcnt, one barrier per K-step; 66 KB of LDS -> two
+// workgroups per CU.  K order: (chunk, taps in the phase order above) -- the generic kernel walks stride-2 convs in the
+// same order (s2_tap_order), so the two are bit-identical.
+
+template <int BN, int RS, bool F8>
+__global__ __launch_bounds__(512) void conv3x3s2_patch_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;
+    constexpr int TH = 8, TW = 16, BM = TH * TW, WM = 4, WN = 2, NW = 8, NT = 512;
+    constexpr int D = RS - 1;                                          // weight tile t+D is issued at step t
+    static_assert(RS == 2 || RS == 3, "ring depth");
+    constexpr int WTN = BN / WN, NI = WTN / 32;
+    constexpr int PWB = TW + 2, PHB = TH + 1, NP = PHB * PWB;          // blocks per patch row (17 used, even pitch) x rows
+    constexpr int P_INSTR = (NP + 8 * NW - 1) / (8 * NW);
+    constexpr int PATCH_BYTES = ((NP * 128 + 1023) / 1024) * 1024;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int B_INSTR = BN / 8 / NW;
+    constexpr int CLD = BN + 4;
+    static_assert(NI >= 1 && B_INSTR >= 1 && NI * 32 * WN == BN, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch0 = smem;
+    char* const bring = smem + 2 * PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.y;
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const bool dual = p.w2 != nullptr;
+    const int SPC = dual ? 10 : 9;                                     // K-steps per channel chunk
+
+    dbg_stamp(p, 0);
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH;
+    const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
+    const int tsp = tile / p.ntn, tn = tile - tsp * p.ntn;
+    const int txi = tsp % tiles_x;
+    const int tyi = (tsp / tiles_x) % tiles_y;
+    const int img = tsp / (tiles_x * tiles_y);
+    const int oy0 = tyi * TH, ox0 = txi * TW, n0 = tn * BN;
+
+    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)g * p.Cin * ES;
+    const int Ktot = 9 * p.Cin;
+    const char* wg = reinterpret_cast<const char*>(p.w) + (size_t)g * p.Cout * Ktot * ES;
+    const char* wg2 = dual ? reinterpret_cast<const char*>(p.w2) + (size_t)g * p.Cout * p.Cin * ES : wg;
+    const int nchunks = p.Cin / CK;
+    const int KT = nchunks * SPC;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wg), 0, (int)((size_t)p.Cout * Ktot * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wg2), 0, (int)((size_t)p.Cout * p.Cin * ES), 0x00020000);
+
+    // patch DMA: LDS patch pixel q = (block row b_r, block col b_c) <- input pixel (2(oy0-1+b_r) + py, 2(ox0-1+b_c) + px);
+    // the phase shift (py, px) is a scalar offset, the block base a per-lane one; blocks outside the image are out of range
+    const bool p_last = (wave + NW * (P_INSTR - 1)) * 8 < NP;
+    unsigned pa_off[P_INSTR];
+#pragma unroll
+    for (int j = 0; j < P_INSTR; ++j) {
+        const int q = (wave + NW * j) * 8 + lrow;
+        const int b_r = q / PWB, b_c = q - b_r * PWB;
+        const int chunk = lpos ^ ((b_c >> 1) & 7);
+        const int by = oy0 - 1 + b_r, bx = ox0 - 1 + b_c;
+        const bool ok = (by >= 0) & (bx >= 0) & (b_c <= TW) & (2 * by + 1 < p.H) & (2 * bx + 1 < p.W);
+        pa_off[j] = ok ? (unsigned)((((long)img * p.H + 2 * by) * p.W + 2 * bx) * p.xcs * ES + chunk * 16) : 0x80000000u;
+    }
+    auto issue_patch = [&](int cc, int ph, int buf) {          // ph: 0 -> (1,1), 1 -> (1,0), 2 -> (0,1), 3 -> (0,0)
+        const int py = ph < 2 ? 1 : 0, px = (ph == 0 || ph == 2) ? 1 : 0;
+        const int soff = (py * p.W + px) * p.xcs * ES + cc * 128;
+        char* dst = patch0 + buf * PATCH_BYTES;
+#pragma unroll
+        for (int j = 0; j < P_INSTR; ++j) {
+            if ((wave + NW * j) * 8 < NP) {
+                if ((wave + NW * j) * 8 + lrow < NP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(dst + (wave + NW * j) * 1024), 16, pa_off[j], soff, 0, 0);
+            }
+        }
+    };
+    unsigned b_off[B_INSTR], b2_off[B_INSTR];
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+        const int n = (wave + NW * j) * 8 + lrow;
+        b_off[j] = (unsigned)((size_t)(n0 + n) * Ktot * ES + (lpos ^ ((n >> 1) & 7)) * 16);
+        b2_off[j] = (unsigned)((size_t)(n0 + n) * p.Cin * ES + (lpos ^ ((n >> 1) & 7)) * 16);
+    }
+    int st_i = 0, st_cc = 0;                                   // cursor of the next weight tile: step index in the chunk, chunk
+    auto issue_b = [&](int slot) {
+        char* dst = bring + slot * B_BYTES;
+        if (st_i < 9) {
+            int tky, tkx;
+            s2_tap(st_i, tky, tkx);
+            const int koff = (tky * 3 + tkx) * p.Cin * ES + st_cc * 128;
+#pragma unroll
+            for (int j = 0; j < B_INSTR; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, W2C_LPTR(dst + (wave + NW * j) * 1024), 16, b_off[j], koff, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < B_INSTR; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, W2C_LPTR(dst + (wave + NW * j) * 1024), 16, b2_off[j], st_cc * 128, 0, 0);
+        }
+        if (++st_i == SPC) { st_i = 0; ++st_cc; }
+    };
+
+    f32x16_t acc[NI], acc2[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; acc2[j][e] = 0.f; }
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tp = wm * 32 + l31;                              // this lane's output pixel of the tile
+    const int tr = tp / TW, tc = tp - tr * TW;
+    const int bswz = (l31 >> 1) & 7;
+    const float* ssp = p.scale + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+    const float* shp = p.shift + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+    const f32x4_t e_sc0 = *reinterpret_cast<const f32x4_t*>(ssp), e_sc1 = *reinterpret_cast<const f32x4_t*>(ssp + 4);
+    const f32x4_t e_sh0 = *reinterpret_cast<const f32x4_t*>(shp), e_sh1 = *reinterpret_cast<const f32x4_t*>(shp + 4);
+
+    // one K-step: fragments of (patch buffer, block shift) x weight slot -> MFMAs into `a`
+    auto kstep = [&](const char* patch, const char* Bs, int dby, int dbx, f32x16_t (&a)[NI]) {
+        const int col = tc + dbx;
+        const char* arow = patch + ((tr + dby) * PWB + col) * 128;
+        const int aswz = (col >> 1) & 7;
+        if constexpr (F8) {
+            i32x8_t fa[2], fb[2][NI];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int c0 = j2 * 4 + lhi * 2;
+                fa[j2] = cat_i32x8(*reinterpret_cast<const u32x4_t*>(arow + ((c0 ^ aswz) << 4)),
+                                   *reinterpret_cast<const u32x4_t*>(arow + (((c0 + 1) ^ aswz) << 4)));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const char* r = Bs + (wn * WTN + j * 32 + l31) * 128;
+                    fb[j2][j] = cat_i32x8(*reinterpret_cast<const u32x4_t*>(r + ((c0 ^ bswz) << 4)),
+                                          *reinterpret_cast<const u32x4_t*>(r + (((c0 + 1) ^ bswz) << 4)));
+                }
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    a[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j2][j], fa[j2], a[j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(a[j]));
+        } else {
+            bf16x8_t fa[4], fb[4][NI];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                fa[kk] = *reinterpret_cast<const bf16x8_t*>(arow + (((kk * 2 + lhi) ^ aswz) << 4));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    fb[kk][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WTN + j * 32 + l31) * 128 + (((kk * 2 + lhi) ^ bswz) << 4));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk], a[j], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline.  Per chunk, step i: 0-3 phase (1,1) | 4,5 phase (1,0) | 6,7 phase (0,1) | 8 phase (0,0) | 9 downsample.
+    // Phase ph of a chunk uses patch buffer ph & 1; patch(ph+1) is issued at the first step of phase ph (right after that
+    // step's weight tile), i.e. >= 2 steps ahead when the downsample step exists.  In-order vmcnt: at the top of step i a
+    // wave may leave in flight the weight tile of step i+1 and a patch issued at step i-1 or i-2 (not needed before i+1).
+    issue_patch(0, 0, 0);
+    issue_b(0);
+    if (D == 2) issue_b(1);
+    int t = 0;
+    auto step = [&](auto itag, int cc) {
+        constexpr int i = decltype(itag)::value;
+        constexpr bool start = (i == 0 || i == 4 || i == 6 || i == 8);
+        // a patch issued at a phase-start step s (after that step's weight tile W(s+D)) is younger than W(t) iff s >= t-D, and
+        // not needed before its own phase starts:
+        constexpr bool patch_in_flight = (i == 1 || (D == 2 && i == 2) || i == 5 || i == 7 || i == 9);
+        if (i == 0 && !dual && t > 0) {
+            wait_vmcnt<0>();                                   // 9-step chunks: this phase's patch was issued one step ago, after W(t+D-1)
+        } else if (t + D - 1 < KT) {
+            if (patch_in_flight && !(i == 9 && cc + 1 >= nchunks)) {
+                if (p_last) wait_vmcnt<(D - 1) * B_INSTR + P_INSTR>(); else wait_vmcnt<(D - 1) * B_INSTR + P_INSTR - 1>();
+            } else {
+                wait_vmcnt<(D - 1) * B_INSTR>();
+            }
+        } else {
+            wait_vmcnt<0>();
+        }
+        pipeline_barrier();
+        if (t == 0) dbg_stamp(p, 1);
+        if (t + D < KT) issue_b((t + D) % RS);
+        if (start) {                                          // next phase's patch: same buffer as the phase that just ended
+            constexpr int ph = (i == 0) ? 0 : (i == 4) ? 1 : (i == 6) ? 2 : 3;
+            if (ph < 3) issue_patch(cc, ph + 1, (ph + 1) & 1);
+            else if (cc + 1 < nchunks) issue_patch(cc + 1, 0, 0);
+        }
+        constexpr int ph_i = (i < 4) ? 0 : (i < 6) ? 1 : (i < 8) ? 2 : 3;
+        constexpr int ky = (i < 9) ? ((const int[9]){0, 0, 2, 2, 0, 2, 1, 1, 1})[i < 9 ? i : 8] : 1;
+        constexpr int kx = (i < 9) ? ((const int[9]){0, 2, 0, 2, 1, 1, 0, 2, 1})[i < 9 ? i : 8] : 1;
+        constexpr int dby = (ky == 0) ? 0 : 1, dbx = (kx == 0) ? 0 : 1;
+        const char* patch = patch0 + (ph_i & 1) * PATCH_BYTES;
+        const char* Bs = bring + (t % RS) * B_BYTES;
+        if (i < 9) kstep(patch, Bs, dby, dbx, acc);
+        else kstep(patch, Bs, 1, 1, acc2);
+        ++t;
+    };
+    for (int cc = 0; cc < nchunks; ++cc) {
+        step(std::integral_constant<int, 0>{}, cc); step(std::integral_constant<int, 1>{}, cc);
+        step(std::integral_constant<int, 2>{}, cc); step(std::integral_constant<int, 3>{}, cc);
+        step(std::integral_constant<int, 4>{}, cc); step(std::integral_constant<int, 5>{}, cc);
+        step(std::integral_constant<int, 6>{}, cc); step(std::integral_constant<int, 7>{}, cc);
+        step(std::integral_constant<int, 8>{}, cc);
+        if (dual) step(std::integral_constant<int, 9>{}, cc);
+    }
+    __syncthreads();
+    dbg_stamp(p, 2);
+
+    // ---- epilogues: conv1 (scale/shift, ReLU, bf16 and/or fp8), then the downsample (scale2/shift2, bf16) ----
+    constexpr int CG = BN / 8;
+    constexpr int PASSES = BM * CG / NT;
+    static_assert(PASSES * NT == BM * CG, "epilogue split");
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int ml = wm * 32 + l31;
+    size_t e_pix[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int r = (ps * NT + tid) / CG;
+        e_pix[ps] = ((size_t)img * p.Ho + oy0 + r / TW) * p.Wo + ox0 + r % TW;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg)
+            *reinterpret_cast<f32x4_t*>(Cs + ml * CLD + wn * WTN + j * 32 + eg * 8 + lhi * 4) =
+                f32x4_t{acc[j][eg * 4], acc[j][eg * 4 + 1], acc[j][eg * 4 + 2], acc[j][eg * 4 + 3]};
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = ps * NT + tid;
+        const int r = idx / CG, cg = idx - r * CG;
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8) * e_sc0 + e_sh0;
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4) * e_sc1 + e_sh1;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const size_t ch = (size_t)g * p.Cout + n0 + cg * 8;
+        store_out8(p, v, e_pix[ps] * p.ycs + (size_t)g * p.ygs + n0 + cg * 8, e_pix[ps] * p.y8cs + ch);
+    }
+    if (dual) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg)
+                *reinterpret_cast<f32x4_t*>(Cs + ml * CLD + wn * WTN + j * 32 + eg * 8 + lhi * 4) =
+                    f32x4_t{acc2[j][eg * 4], acc2[j][eg * 4 + 1], acc2[j][eg * 4 + 2], acc2[j][eg * 4 + 3]};
+        __syncthreads();
+        const float* ssp2 = p.scale2 + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+        const float* shp2 = p.shift2 + g * p.Cout + n0 + (tid % (BN / 8)) * 8;
+        const f32x4_t sc0 = *reinterpret_cast<const f32x4_t*>(ssp2), sc1 = *reinterpret_cast<const f32x4_t*>(ssp2 + 4);
+        const f32x4_t sh0 = *reinterpret_cast<const f32x4_t*>(shp2), sh1 = *reinterpret_cast<const f32x4_t*>(shp2 + 4);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int idx = ps * NT + tid;
+            const int r = idx / CG, cg = idx - r * CG;
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8) * sc0 + sh0;
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(Cs + r * CLD + cg * 8 + 4) * sc1 + sh1;
+            uint4 o;
+            o.x = pack_bf16x2(v0[0], v0[1]); o.y = pack_bf16x2(v0[2], v0[3]);
+            o.z = pack_bf16x2(v1[0], v1[1]); o.w = pack_bf16x2(v1[2], v1[3]);
+            *reinterpret_cast<uint4*>(p.y2 + e_pix[ps] * p.y2cs + (size_t)g * p.Cout + n0 + cg * 8) = o;
+        }
+    }
+    dbg_stamp(p, 3);
+#endif
+}
+
+template <int BN, int RS, bool F8>
+int launch_s2patch(ConvArgs& a, int groups, hipStream_t s) {
+    constexpr int CK = OpT<F8>::CK;
+    if (a.ks != 3 || a.stride != 2 || a.Cin % CK != 0 || a.Cout % BN != 0 || a.Ho % 8 != 0 || a.Wo % 16 != 0 || (a.H & 1) || (a.W & 1) ||
+        a.res)                                                 // (a block's conv1 has no residual; the kernel has no path for one)
+        return W2C_E_ARG;
+    a.ntm = a.M * (a.Ho / 8) * (a.Wo / 16);
+    a.ntn = a.Cout / BN;
+    constexpr int patch = ((9 * 18 * 128 + 1023) / 1024) * 1024;
+    constexpr int ring = 2 * patch + RS * BN * 128;
+    constexpr int epi = 128 * (BN + 4) * 4;
+    constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static unsigned long long attr_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_patch_kernel<BN, RS, F8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_mask |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL((conv3x3s2_patch_kernel<BN, RS, F8>), dim3(a.ntm * a.ntn, groups), dim3(512), lds, s, a);
+    return w2c_launch_status();
+}
 
 // =====================================================================================================
 // Layer1 kernel: 3x3 stride-1, Cin = Cout = 64 per group, weights stationary in REGISTERS.
@@ -1379,6 +1703,10 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
+        // stride-2 3x3 on polyphase halo patches (here without the fused downsample)
+        case 60: return launch_s2patch<64, 3, false>(a, groups, s);
+        case 61: return launch_s2patch<128, 2, false>(a, groups, s);
+        case 62: return launch_s2patch<64, 2, false>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -1394,6 +1722,8 @@ int launch_variant_f8(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 36: return launch_patch<8, 16, 64, 4, 2, 3, 2, true>(a, groups, s);
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1, true>(a, groups, s);      // Cin == 128: one chunk
         case 40: return launch_patch<8, 16, 128, 2, 2, 2, 1, true>(a, groups, s);     // Cin == 128, 128 channels per tile
+        case 60: return launch_s2patch<64, 3, true>(a, groups, s);
+        case 61: return launch_s2patch<128, 2, true>(a, groups, s);
         default: return W2C_E_ARG;
     }
 }
@@ -1401,6 +1731,9 @@ int launch_variant_f8(int variant, ConvArgs& a, int groups, hipStream_t s) {
 int pick_variant_f8(const ConvArgs& a, int groups) {
     const long rows = a.rows;
     const int Cout = a.Cout;
+    if (a.stride == 2 && a.ks == 3 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && Cout % 64 == 0 && !(a.H & 1) && !(a.W & 1) && !a.res &&
+        !getenv("W2C_NO_S2PATCH"))
+        return 60;
     if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
         if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 40;
@@ -1435,6 +1768,9 @@ int pick_variant(const ConvArgs& a, int groups) {
         if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
         if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;
     }
+    if (a.stride == 2 && a.ks == 3 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && Cout % 64 == 0 && !(a.H & 1) && !(a.W & 1) && !a.ws &&
+        !a.res && !getenv("W2C_NO_S2PATCH"))
+        return 60;
     // stride-2 3x3: the 128x64 tile beats 128x128 at every cfg-2 shape (tools/bench_s2_block.py: 46.1 / 36.9 / 36.5 us vs
     // 47.7 / 42.8 / 38.1 us) -- twice the workgroups for a kernel whose K-step is dominated by the 9x re-gather of its rows
     if (a.stride == 2 && a.ks == 3 && Cout % 64 == 0 && (rows / 128) * (Cout / 64) * groups >= 512) return 3;
@@ -1592,6 +1928,13 @@ extern "C" int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int 
     if (!w1 || !scale1 || !shift1 || !idt_bf16 || idt_cstride < groups * Cout || (idt_cstride % 8) != 0) return W2C_E_ARG;
     a.w2 = reinterpret_cast<const uint16_t*>(w1); a.scale2 = scale1; a.shift2 = shift1; a.y2 = idt_bf16; a.y2cs = idt_cstride;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // maps that tile into 8 x 16 output pixels go to the polyphase halo-patch kernel (variant 60), the rest to the generic
+    // DUAL kernel; both walk K in the same order, so the choice never shows in the bits
+    const bool patch_ok = a.Ho % 8 == 0 && a.Wo % 16 == 0 && Cout % 64 == 0 && !(H & 1) && !(W & 1);
+    if (variant == 60 || (variant < 0 && patch_ok && !getenv("W2C_NO_S2PATCH")))
+        return x_is_fp8 ? launch_s2patch<64, 3, true>(a, groups, s) : launch_s2patch<64, 3, false>(a, groups, s);
+    if (variant == 61) return x_is_fp8 ? launch_s2patch<128, 2, true>(a, groups, s) : launch_s2patch<128, 2, false>(a, groups, s);
+    if (variant == 62) return x_is_fp8 ? launch_s2patch<64, 2, true>(a, groups, s) : launch_s2patch<64, 2, false>(a, groups, s);
     return x_is_fp8 ? launch_dual<true>(a, groups, variant, s) : launch_dual<false>(a, groups, variant, s);
 }
 

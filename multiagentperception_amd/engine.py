@@ -129,11 +129,12 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
         if f8:
             return c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1], None
         return c1.run(x, x_ch_off=x_ch_off), x
-    # one launch pays on the larger maps only (tools/bench_s2_block.py, cfg 2: layer2.0 61.7 vs 67.9 us, layer3.0 52.0 vs
-    # 57.3 us, layer4.0 55.1 vs 48.0 us): below ~16 k output pixels the two kernels' smaller register footprint wins.
-    # Either way the bits are the same.
+    # one launch: the polyphase halo-patch kernel where the output map tiles into 8 x 16 pixels (tools/bench_s2_block.py, cfg 2:
+    # layer2.0 57-60 us vs 70.6 for the two launches, layer3.0 46.0 vs 57.1, layer4.0 48.3 vs 54.2), else the generic DUAL
+    # kernel when the map is large enough to pay for its second accumulator set (>= 16 k output pixels).  Same bits either way.
     Ho, Wo = (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2
-    if os.environ.get("W2C_NO_DUAL") or x.shape[0] * Ho * Wo < 16384:
+    patch_ok = Ho % 8 == 0 and Wo % 16 == 0 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+    if os.environ.get("W2C_NO_DUAL") or not (patch_ok or x.shape[0] * Ho * Wo >= 16384):
         if f8:
             return (c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1],
                     ds.run(x, x_ch_off=x_ch_off)[0])

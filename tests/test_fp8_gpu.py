@@ -143,7 +143,7 @@ def test_conv_fp8_result_is_independent_of_variant_and_image_count(cin, cout, hw
     res = torch.randn(M, ho, ho, G * cout, generator=gen).to(BF16).to(_dev())
     f16, f8 = ops.conv_fp8(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, out_fp8_scale=0.05)
     tried = 0
-    for v in (0, 3, 6, 36, 38, 40):
+    for v in (0, 3, 6, 36, 38, 40, 60, 61):
         try:
             a16, a8 = ops.conv_fp8(x, 0, cin, w, cout, ks, stride, G, sc, sh, residual=res, out_fp8_scale=0.05, variant=v)
         except W2CError:
@@ -168,7 +168,9 @@ def test_fp8_stride2_block_front_in_one_launch_equals_the_two_convs(cin, cout, h
     sh3, sh1 = [(torch.randn(G * cout, generator=gen) * 0.1).to(_dev()) for _ in range(2)]
     _, t8_ref = ops.conv_fp8(x, 0, cin, w3, cout, 3, 2, G, sc3, sh3, relu=True, out_bf16=False, out_fp8_scale=0.02)
     i_ref, _ = ops.conv_fp8(x, 0, cin, w1, cout, 1, 2, G, sc1, sh1, relu=False)
-    for v in (-1, 0, 3, 6):
+    for v in (-1, 0, 3, 6, 60, 61):
+        if v >= 60 and (hw // 2) % 16:
+            continue
         t, t8, idt = ops.conv_s2_block(x, 0, cin, w3, sc3, sh3, w1, sc1, sh1, cout, G, t_bf16=False, t_fp8_scale=0.02, variant=v)
         assert t is None and torch.equal(t8, t8_ref) and torch.equal(idt, i_ref), "variant %d" % v
 
