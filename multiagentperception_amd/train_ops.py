@@ -99,7 +99,7 @@ class _Conv2dHipFn(torch.autograd.Function):
             if dx.dtype != ctx.in_dtype:
                 dx = dx.to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(xh, 0, cin, gyh, cout, k, ctx.stride, 1).reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+            dw = ops.conv_wgrad(xh, 0, cin, gyh, cout, k, ctx.stride, 1).reshape(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gyh.float().sum(dim=(0, 1, 2))
         return dx, dw, db, None
