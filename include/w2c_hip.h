@@ -174,7 +174,14 @@ long long w2c_conv_wgrad_workspace_bytes(int M, int H, int W, int Cin, int Cout,
 int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
                         const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride, int groups,
                         float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream);
+/* the same with groups = 1 and dw written in nn.Conv2d's parameter layout [Cout][Cin][ky][kx] (what autograd hands the optimiser) */
+int w2c_conv_wgrad_bf16_oihw(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                             const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride,
+                             float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream);
 int w2c_zero_insert2_bf16(const uint16_t* dy, int M, int Ho, int Wo, int C, uint16_t* u, int H, int W, w2c_stream_t stream);
+/* nn.Conv2d's f32 parameter [Cout][Cin][ky][kx] (Cout, Cin multiples of 32; ksize 1 or 3) -> the packed bf16 operand of
+ * w2c_conv_igemm_bf16: mode 0 = forward [Cout][tap][Cin]; mode 1 = input-gradient [Cin][taps-1-tap][Cout]. */
+int w2c_pack_conv_weights_bf16(const float* w_oihw, int Cout, int Cin, int ksize, int mode, uint16_t* out, w2c_stream_t stream);
 
 /* ---- SURVEY 8f rank 3, stage 2: train-mode BatchNorm2d (batch statistics over all P = M*H*W pixels of the
  * agent-concatenated batch, agent.py:1108-1111) fused with the residual add and ReLU that follow it in
@@ -282,6 +289,23 @@ int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstri
 /* Adjoint of K9 for the training backward: gout f32 NCHW [M, n_classes, 32h, 32w] ->
  * glow f32 NCHW [M, n_classes, h, w] = d loss / d (the low-resolution logits), same source-index rule; deterministic. */
 int w2c_upsample_bilinear32_backward(const float* gout, int M, int h, int w, int n_classes, float* glow, w2c_stream_t stream);
+
+/* ---- cross_entropy2d (ptsemseg/loss/loss.py:5-18 = F.cross_entropy(NCHW logits -> [P, C], target,
+ * weight, size_average, ignore_index)) forward and backward.
+ * logits : f32 NCHW [N, C, HW]; target : int64 [N, HW]; weight : f32 [C] or NULL.
+ * Forward: lse f32 [N*HW] (log-sum-exp per pixel, kept for the backward), loss_px f32 [N*HW] or NULL (w_t * nll per pixel, 0
+ * where ignored: the reduce=False form bootstrapped_cross_entropy2d loss.py:51-53 tops), out3 f32 [3] = {loss, denominator
+ * (sum of kept w_t), count of targets outside [0,C) that are not ignore_index (dropped)}; loss = sum / denominator when
+ * size_average else the sum.  workspace >= w2c_cross_entropy2d_workspace_bytes(N*HW).  Deterministic.
+ * Backward: dlogits f32 NCHW = g * w_t * (softmax - onehot) on kept pixels, 0 elsewhere; g = gout[0] (device scalar or NULL = 1)
+ * / denom[0] (device scalar = out3 + 1, or NULL) * gpx[pixel] (or NULL). */
+long long w2c_cross_entropy2d_workspace_bytes(long long n_pixels);
+int w2c_cross_entropy2d_forward(const float* logits, const long long* target, const float* weight, int N, int C, long long HW,
+                                int ignore_index, int size_average, float* lse, float* loss_px, float* out3,
+                                void* workspace, long long workspace_bytes, w2c_stream_t stream);
+int w2c_cross_entropy2d_backward(const float* logits, const long long* target, const float* weight, const float* lse, int N,
+                                 int C, long long HW, int ignore_index, const float* denom, const float* gout,
+                                 const float* gpx, float* dlogits, w2c_stream_t stream);
 
 /* ---- SURVEY 8f row 4 (output side): K9 fused with the evaluator's class argmax (trainer.py:804
  * `outputs.data.max(1)[1]`): labels u8 [M, 32h, 32w] = argmax over classes of the bilinear x32 upsample of `low`

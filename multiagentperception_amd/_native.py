@@ -38,6 +38,8 @@ SIGNATURES = {
                           _vp, _i, _vp],
     "w2c_conv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_conv_wgrad_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _ll, _vp],
+    "w2c_conv_wgrad_bf16_oihw": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _ll, _vp],
+    "w2c_pack_conv_weights_bf16": [_vp, _i, _i, _i, _i, _vp, _vp],
     "w2c_zero_insert2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "w2c_bn_workspace_bytes": [_ll, _i],
     "w2c_bn_train_forward": [_vp, _ll, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
@@ -55,6 +57,9 @@ SIGNATURES = {
     "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample32_argmax": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample_bilinear32_backward": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "w2c_cross_entropy2d_workspace_bytes": [_ll],
+    "w2c_cross_entropy2d_forward": [_vp, _vp, _vp, _i, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp],
+    "w2c_cross_entropy2d_backward": [_vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp],
     "w2c_upsample32_argmax_confusion": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "w2c_confusion_matrix": [_vp, _i, _vp, _ll, _i, _vp, _vp],
     "w2c_nchw_f32_to_nhwc_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp],
@@ -89,7 +94,8 @@ def lib():
                 raise W2CError("libw2c_hip.so does not export %s (stale build?)" % name)
             fn.argtypes = argtypes
             fn.restype = (_c.c_char_p if name in ("w2c_status_string", "w2c_last_error_string") else
-                          _c.c_longlong if name in ("w2c_conv_splitk_workspace_bytes", "w2c_conv_wgrad_workspace_bytes", "w2c_bn_workspace_bytes") else _i)
+                          _c.c_longlong if name in ("w2c_conv_splitk_workspace_bytes", "w2c_conv_wgrad_workspace_bytes", "w2c_bn_workspace_bytes",
+                                                     "w2c_cross_entropy2d_workspace_bytes") else _i)
         _lib = handle
     return _lib
 

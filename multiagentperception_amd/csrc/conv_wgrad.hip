@@ -168,6 +168,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     reinterpret_cast<f32x4_t*>(dw)[i] = s;
 }
 
+// the same reduction, written in nn.Conv2d's parameter layout [Cout][Cin][ky][kx] (groups = 1) so that the optimiser reads the
+// gradient where autograd expects it, with no permute copy in between.  i indexes 4 consecutive ci of one (co, tap).
+__global__ __launch_bounds__(256) void wgrad_reduce_oihw_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int nseg,
+                                                                 int taps, int cin) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4_t s = reinterpret_cast<const f32x4_t*>(ws)[i];
+    for (int k = 1; k < nseg; ++k) s += reinterpret_cast<const f32x4_t*>(ws)[(size_t)k * n4 + i];
+    const long e = i * 4;                          // = (co * taps + tap) * cin + ci
+    const int ci = (int)(e % cin);
+    const long ct = e / cin;
+    const int tap = (int)(ct % taps);
+    const long co = ct / taps;
+    float* d = dw + (co * cin + ci) * taps + tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[(long)j * taps] = s[j];
+}
+
+// nn.Conv2d's f32 parameter [Cout][Cin][ky][kx] -> the kernels' packed bf16 operand, one launch (the torch formulation is a
+// permute copy + a cast (+ a flip): three passes and three launches per conv and step):
+//   mode 0 (forward)  out[co][tap][ci]
+//   mode 1 (dgrad)    out[ci][taps-1-tap][co]      (flipped taps, transposed channels)
+// A workgroup moves a 32(co) x 32(ci) x taps block through LDS: reads are runs of 32*taps consecutive floats, writes runs of
+// 32 consecutive bf16.
+template <int T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int mode) {
+    __shared__ float tile[32 * 32 * T];
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    for (int r = threadIdx.x; r < 32 * 32 * T; r += 256) {
+        const int co_l = r / (32 * T), rem = r - co_l * (32 * T);
+        tile[r] = w[((long)(co0 + co_l) * Cin + ci0) * T + rem];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 32 * 32 * T; o += 256) {
+        const int a = o / (32 * T), t = (o >> 5) % T, b = o & 31;
+        if (mode == 0) out[((long)(co0 + a) * T + t) * Cin + ci0 + b] = f32_to_bf16(tile[a * 32 * T + b * T + t]);
+        else out[((long)(ci0 + a) * T + t) * Cout + co0 + b] = f32_to_bf16(tile[b * 32 * T + a * T + (T - 1 - t)]);
+    }
+}
+
 // dY (stride-2 conv output grid) -> zero-inserted tensor on the input grid: u[m][2oy][2ox] = dy[m][oy][ox], 0 elsewhere;
 // the stride-2 conv's input gradient is then a stride-1 conv of u with the flipped, transposed weights.
 __global__ __launch_bounds__(256) void zero_insert2_kernel(const uint4* __restrict__ dy, uint4* __restrict__ u, int M, int Ho, int Wo, int H,
@@ -208,9 +248,9 @@ extern "C" long long w2c_conv_wgrad_workspace_bytes(int M, int H, int W, int Cin
     return nseg * (long long)groups * Cout * ksize * ksize * Cin * 4;
 }
 
-extern "C" int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
-                                   const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride, int groups,
-                                   float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream) {
+static int wgrad_impl(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                      const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride, int groups,
+                      float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream, bool oihw) {
     w2c_clear_error();
     if (!x || !dy || !dw || !workspace) return W2C_E_ARG;
     const long long need = w2c_conv_wgrad_workspace_bytes(M, H, W, Cin, Cout, ksize, stride, groups);
@@ -238,7 +278,32 @@ extern "C" int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int C
     int rc = w2c_launch_status();
     if (rc != W2C_OK) return rc;
     const long n4 = per / 16;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.ws, dw, n4, a.nseg);
+    if (oihw) hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.ws, dw, n4, a.nseg,
+                                 ksize * ksize, Cin);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.ws, dw, n4, a.nseg);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_conv_wgrad_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                   const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride, int groups,
+                                   float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream) {
+    return wgrad_impl(x, M, H, W, Cin, x_cstride, dy, Cout, dy_cstride, ksize, stride, groups, dw, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int w2c_conv_wgrad_bf16_oihw(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                        const uint16_t* dy, int Cout, int dy_cstride, int ksize, int stride,
+                                        float* dw, void* workspace, long long workspace_bytes, w2c_stream_t stream) {
+    return wgrad_impl(x, M, H, W, Cin, x_cstride, dy, Cout, dy_cstride, ksize, stride, 1, dw, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int w2c_pack_conv_weights_bf16(const float* w_oihw, int Cout, int Cin, int ksize, int mode, uint16_t* out, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!w_oihw || !out || Cout <= 0 || Cin <= 0 || (Cout % 32) || (Cin % 32) || (ksize != 1 && ksize != 3) || (mode != 0 && mode != 1))
+        return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(Cin / 32, Cout / 32);
+    if (ksize == 3) hipLaunchKernelGGL((pack_weights_kernel<9>), grid, dim3(256), 0, s, w_oihw, out, Cout, Cin, mode);
+    else hipLaunchKernelGGL((pack_weights_kernel<1>), grid, dim3(256), 0, s, w_oihw, out, Cout, Cin, mode);
     return w2c_launch_status();
 }
 

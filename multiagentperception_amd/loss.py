@@ -1,0 +1,122 @@
+"""Loss functions of the reference's training loop on the HIP kernels.
+
+Mirrors ``ptsemseg/loss/loss.py`` and ``ptsemseg/loss/__init__.py`` of the reference: same names, arguments and registry
+(`get_loss_function(cfg)`, keys ``cross_entropy`` / ``bootstrapped_cross_entropy`` / ``multi_scale_cross_entropy``), so
+``train.py:190`` and ``trainer.py:671`` (``loss = self.loss_fn(input=outputs, target=labels)``) run unchanged.
+
+On GPU tensors the pixel-wise cross entropy (ignore_index 250, optional class weights) runs on
+``w2c_cross_entropy2d_forward`` / ``_backward`` (csrc/loss.hip): one read of the logits forward, one read + one write
+backward, deterministic.  CPU tensors take torch's own ``F.cross_entropy`` -- the reference's semantics on a device this
+package does not target (there is no HIP library involved on that branch, hence nothing to fall back from).
+"""
+import functools
+import logging
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+logger = logging.getLogger("ptsemseg")
+IGNORE_INDEX = 250          # loss.py:16
+
+
+class _CrossEntropy2dFn(torch.autograd.Function):
+    """mean (or sum) of w_t * nll over the kept pixels.  Inputs: logits NCHW f32 contiguous, target int64 [N,H,W]."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight, size_average):
+        out3, lse, _ = ops.cross_entropy2d_forward(logits, target, weight, size_average, IGNORE_INDEX)
+        ctx.save_for_backward(logits, target, lse, out3)
+        ctx.weight, ctx.size_average = weight, size_average
+        return out3[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, lse, out3 = ctx.saved_tensors
+        denom = out3[1:2] if ctx.size_average else None
+        g = gout.detach().reshape(1).float().contiguous()
+        return ops.cross_entropy2d_backward(logits, target, ctx.weight, lse, denom, g, None, IGNORE_INDEX), None, None, None
+
+
+class _CrossEntropy2dPixelsFn(torch.autograd.Function):
+    """reduce=False form: the per-pixel w_t * nll map [N,H,W] (0 at ignored pixels), for the bootstrapped loss."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        _, lse, px = ops.cross_entropy2d_forward(logits, target, weight, False, IGNORE_INDEX, per_pixel=True)
+        ctx.save_for_backward(logits, target, lse)
+        ctx.weight = weight
+        return px
+
+    @staticmethod
+    def backward(ctx, gpx):
+        logits, target, lse = ctx.saved_tensors
+        return ops.cross_entropy2d_backward(logits, target, ctx.weight, lse, None, None, gpx.detach().float().contiguous(),
+                                            IGNORE_INDEX), None, None
+
+
+def _prep(input, target, weight):
+    logits = input if input.dtype == torch.float32 else input.float()
+    w = None if weight is None else weight.to(device=logits.device, dtype=torch.float32).contiguous()
+    return logits.contiguous(), target.long().contiguous(), w
+
+
+def cross_entropy2d(input, target, weight=None, size_average=True):
+    """loss.py:5-18.  input [n,c,h,w] logits, target [n,ht,wt] labels (250 = ignore)."""
+    n, c, h, w = input.size()
+    nt, ht, wt = target.size()
+    if h != ht and w != wt:                 # loss.py:10-11: labels at another resolution -> resample the logits
+        input = F.interpolate(input, size=(ht, wt), mode="bilinear", align_corners=True)
+    if not input.is_cuda:
+        flat = input.transpose(1, 2).transpose(2, 3).contiguous().view(-1, c)
+        return F.cross_entropy(flat, target.view(-1), weight=weight, reduction="mean" if size_average else "sum",
+                               ignore_index=IGNORE_INDEX)
+    logits, tgt, wgt = _prep(input, target, weight)
+    return _CrossEntropy2dFn.apply(logits, tgt, wgt, bool(size_average))
+
+
+def multi_scale_cross_entropy2d(input, target, weight=None, size_average=True, scale_weight=None):
+    """loss.py:21-38: auxiliary-head weighting (1, 0.4, 0.16, ...) when the model returns a tuple."""
+    if not isinstance(input, tuple):
+        return cross_entropy2d(input=input, target=target, weight=weight, size_average=size_average)
+    if scale_weight is None:
+        n_inp = len(input)
+        scale_weight = torch.pow(0.4 * torch.ones(n_inp), torch.arange(n_inp).float()).to(target.device)
+    loss = 0.0
+    for i, inp in enumerate(input):
+        loss = loss + scale_weight[i] * cross_entropy2d(input=inp, target=target, weight=weight, size_average=size_average)
+    return loss
+
+
+def bootstrapped_cross_entropy2d(input, target, K, weight=None, size_average=True):
+    """loss.py:41-69: per image, the mean of the K largest pixel losses; averaged over the batch."""
+    batch_size = input.size()[0]
+    if input.is_cuda:
+        logits, tgt, wgt = _prep(input, target, weight)
+        px = _CrossEntropy2dPixelsFn.apply(logits, tgt, wgt).view(batch_size, -1)
+    else:
+        px = F.cross_entropy(input, target, weight=weight, reduction="none", ignore_index=IGNORE_INDEX).view(batch_size, -1)
+    topk, _ = px.topk(K, dim=1)
+    return (topk.sum(dim=1) / K).sum() / float(batch_size)
+
+
+key2loss = {
+    "cross_entropy": cross_entropy2d,
+    "bootstrapped_cross_entropy": bootstrapped_cross_entropy2d,
+    "multi_scale_cross_entropy": multi_scale_cross_entropy2d,
+}
+
+
+def get_loss_function(cfg):
+    """ptsemseg/loss/__init__.py:22-37."""
+    if cfg["training"]["loss"] is None:
+        logger.info("Using default cross entropy loss")
+        return cross_entropy2d
+    loss_dict = cfg["training"]["loss"]
+    loss_name = loss_dict["name"]
+    loss_params = {k: v for k, v in loss_dict.items() if k != "name"}
+    if loss_name not in key2loss:
+        raise NotImplementedError("Loss {} not implemented".format(loss_name))
+    logger.info("Using {} with {} params".format(loss_name, loss_params))
+    return functools.partial(key2loss[loss_name], **loss_params)

@@ -380,7 +380,20 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
 _wgrad_ws = {}
 
 
-def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups):
+def pack_conv_weights(weight, mode):
+    """nn.Conv2d weight f32 [Cout,Cin,k,k] -> packed bf16 operand: mode 0 [1, Cout, k*k*Cin] (forward), mode 1
+    [1, Cin, k*k*Cout] (flipped + transposed: the input-gradient conv).  include/w2c_hip.h w2c_pack_conv_weights_bf16."""
+    dev = _need_gpu(weight)
+    co, ci, k, k2 = weight.shape
+    if weight.dtype != torch.float32 or not weight.is_contiguous() or k != k2:
+        raise W2CError("pack_conv_weights: contiguous f32 [Cout,Cin,k,k] expected")
+    out = torch.empty((1, co if mode == 0 else ci, k * k * (ci if mode == 0 else co)), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_pack_conv_weights_bf16(_p(weight), co, ci, k, mode, _p(out), _stream(dev)), "w2c_pack_conv_weights_bf16")
+    return out
+
+
+def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups, oihw=False):
     """dW f32 [G, cout, ksize*ksize*cin] of the conv that maps x (bf16 NHWC, channels [x_ch_off, +G*cin)) to an output whose
     gradient is dy (bf16 NHWC [M,Ho,Wo,G*cout]).  include/w2c_hip.h w2c_conv_wgrad_bf16."""
     dev = _need_gpu(x, dy)
@@ -399,6 +412,15 @@ def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups):
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(int(need), 32 << 20), dtype=torch.uint8, device=dev)
         _wgrad_ws[key] = ws
+    if oihw:                    # nn.Conv2d's parameter layout (groups = 1): what autograd returns for `weight`
+        if groups != 1:
+            raise W2CError("conv_wgrad: the OIHW form is for groups = 1")
+        dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_native.lib().w2c_conv_wgrad_bf16_oihw(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(dy), cout, dy.shape[3],
+                                                         ksize, stride, _p(dw), _p(ws), ws.numel(), _stream(dev)),
+                  "w2c_conv_wgrad_bf16_oihw")
+        return dw
     dw = torch.empty((groups, cout, ksize * ksize * cin), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_conv_wgrad_bf16(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(dy), cout, dy.shape[3], ksize,
@@ -601,6 +623,50 @@ def upsample_bilinear32_backward(gout):
         check(_native.lib().w2c_upsample_bilinear32_backward(_p(gout), M, H // 32, W // 32, C, _p(glow), _stream(dev)),
               "w2c_upsample_bilinear32_backward")
     return glow
+
+
+def cross_entropy2d_forward(logits, target, weight=None, size_average=True, ignore_index=250, per_pixel=False):
+    """logits f32 NCHW [N,C,H,W] (contiguous), target int64 [N,H,W], weight f32 [C] or None ->
+    (out3 f32 [3] = {loss, denominator, dropped out-of-range targets}, lse f32 [N,H,W], loss_px f32 [N,H,W] or None)."""
+    dev = _need_gpu(logits)
+    N, C, H, W = logits.shape
+    if (logits.dtype != torch.float32 or not logits.is_contiguous() or target.dtype != torch.int64 or not target.is_contiguous()
+            or tuple(target.shape) != (N, H, W) or target.device != dev):
+        raise W2CError("cross_entropy2d: contiguous f32 NCHW logits and int64 [N,H,W] target on one device expected")
+    if weight is not None and (weight.dtype != torch.float32 or weight.numel() != C or weight.device != dev or not weight.is_contiguous()):
+        raise W2CError("cross_entropy2d: weight must be f32 [C] on the logits' device")
+    lib = _native.lib()
+    lse = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    loss_px = torch.empty((N, H, W), dtype=torch.float32, device=dev) if per_pixel else None
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    nbytes = lib.w2c_cross_entropy2d_workspace_bytes(N * H * W)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.w2c_cross_entropy2d_forward(_p(logits), _p(target), _p(weight) if weight is not None else None, N, C, H * W,
+                                              ignore_index, 1 if size_average else 0, _p(lse),
+                                              _p(loss_px) if per_pixel else None, _p(out3), _p(ws), nbytes, _stream(dev)),
+              "w2c_cross_entropy2d_forward")
+    return out3, lse, loss_px
+
+
+def cross_entropy2d_backward(logits, target, weight, lse, denom=None, gout=None, gpx=None, ignore_index=250):
+    """-> d loss / d logits, f32 NCHW; denom / gout: 1-element f32 device tensors (or None), gpx: f32 [N,H,W] or None."""
+    dev = _need_gpu(logits)
+    N, C, H, W = logits.shape
+    for t in (denom, gout, gpx):
+        if t is not None and (t.dtype != torch.float32 or t.device != dev or not t.is_contiguous()):
+            raise W2CError("cross_entropy2d backward: f32 contiguous scale tensors on the logits' device expected")
+    if gpx is not None and gpx.numel() != N * H * W:
+        raise W2CError("cross_entropy2d backward: gpx must have one entry per pixel")
+    d = torch.empty_like(logits)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_cross_entropy2d_backward(_p(logits), _p(target), _p(weight) if weight is not None else None,
+                                                         _p(lse), N, C, H * W, ignore_index,
+                                                         _p(denom) if denom is not None else None,
+                                                         _p(gout) if gout is not None else None,
+                                                         _p(gpx) if gpx is not None else None, _p(d), _stream(dev)),
+              "w2c_cross_entropy2d_backward")
+    return d
 
 
 def upsample32_argmax(low, n_classes):

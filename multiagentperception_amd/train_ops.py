@@ -56,13 +56,23 @@ def _nhwc_bf16(x):
 
 
 def _pack_fwd(weight):
-    co = weight.shape[0]
-    return weight.detach().permute(0, 2, 3, 1).reshape(1, co, -1).to(BF16).contiguous()          # [1][Cout][tap][Cin]
+    return ops.pack_conv_weights(weight.detach().float().contiguous(), 0)          # [1][Cout][tap][Cin]
 
 
 def _pack_dgrad(weight):
-    ci = weight.shape[1]
-    return weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(1, ci, -1).to(BF16).contiguous()   # [1][Cin][2-ky,2-kx][Cout]
+    return ops.pack_conv_weights(weight.detach().float().contiguous(), 1)          # [1][Cin][2-ky,2-kx][Cout]
+
+
+_consts = {}
+
+
+def _const(dev, n, value):
+    """cached read-only f32 [n] of `value` (the convs' unit scales / zero shifts: ~200 fill launches per step otherwise)"""
+    key = (dev, n, value)
+    t = _consts.get(key)
+    if t is None:
+        t = _consts[key] = torch.full((n,), value, dtype=torch.float32, device=dev)
+    return t
 
 
 class _Conv2dHipFn(torch.autograd.Function):
@@ -71,8 +81,8 @@ class _Conv2dHipFn(torch.autograd.Function):
         cout, cin, k, _ = weight.shape
         xh = _nhwc_bf16(x)
         dev = xh.device
-        ones = torch.ones(cout, device=dev)
-        shift = bias.detach().float() if bias is not None else torch.zeros(cout, device=dev)
+        ones = _const(dev, cout, 1.0)
+        shift = bias.detach().float() if bias is not None else _const(dev, cout, 0.0)
         M, H, W, _ = xh.shape
         Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
         # the result is allocated as a logical-NCHW channels_last tensor and the kernel writes its NHWC view: the Function
@@ -94,12 +104,12 @@ class _Conv2dHipFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             src = gyh if ctx.stride == 1 else ops.zero_insert2(gyh, H, W)
             dx = torch.empty((M, cin, H, W), dtype=BF16, device=dev, memory_format=torch.channels_last)
-            ops.conv_igemm(src, 0, cout, _pack_dgrad(weight), cin, k, 1, 1, torch.ones(cin, device=dev),
-                           torch.zeros(cin, device=dev), relu=False, out=dx.permute(0, 2, 3, 1))
+            ops.conv_igemm(src, 0, cout, _pack_dgrad(weight), cin, k, 1, 1, _const(dev, cin, 1.0),
+                           _const(dev, cin, 0.0), relu=False, out=dx.permute(0, 2, 3, 1))
             if dx.dtype != ctx.in_dtype:
                 dx = dx.to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(xh, 0, cin, gyh, cout, k, ctx.stride, 1).reshape(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
+            dw = ops.conv_wgrad(xh, 0, cin, gyh, cout, k, ctx.stride, 1, oihw=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gyh.float().sum(dim=(0, 1, 2))
         return dx, dw, db, None

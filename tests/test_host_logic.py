@@ -237,3 +237,24 @@ def test_query_projection_folded_into_key_head_is_the_same_algebra():
     np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), atol=2e-5, rtol=1e-5)
     # the query head is untouched
     np.testing.assert_array_equal(hp.tails[1][3].numpy(), qhead.fc[4].weight.detach().t().contiguous().numpy())
+
+
+def test_loss_registry_mirrors_the_reference_and_cpu_tensors_use_torch():
+    """ptsemseg/loss/__init__.py:14-37: same keys, default, functools.partial of the yml's parameters, unknown name raises."""
+    import functools
+    import torch.nn.functional as F
+    from ptsemseg.loss import get_loss_function, key2loss
+    from ptsemseg.loss.loss import cross_entropy2d
+    assert set(key2loss) == {"cross_entropy", "bootstrapped_cross_entropy", "multi_scale_cross_entropy"}
+    assert get_loss_function({"training": {"loss": None}}) is cross_entropy2d
+    fn = get_loss_function({"training": {"loss": {"name": "bootstrapped_cross_entropy", "K": 16}}})
+    assert isinstance(fn, functools.partial) and fn.keywords == {"K": 16}
+    with pytest.raises(NotImplementedError):
+        get_loss_function({"training": {"loss": {"name": "dice"}}})
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 11, 8, 8, generator=g, requires_grad=True)
+    t = torch.randint(0, 11, (2, 8, 8), generator=g)
+    t[0, 0, :4] = 250
+    want = F.cross_entropy(x, t, ignore_index=250)
+    assert torch.allclose(cross_entropy2d(input=x, target=t), want)
+    assert float(fn(input=x, target=t)) > float(want)          # the mean of the 16 hardest pixels exceeds the mean of all

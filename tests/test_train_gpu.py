@@ -48,6 +48,19 @@ def test_conv_wgrad_matches_autograd(case):
         ref = w.grad.float()
         scale = float(ref.abs().max())
         np.testing.assert_allclose(got[g].numpy(), ref.numpy(), atol=2e-4 * scale + 1e-4, rtol=2e-4)
+    if G == 1:          # the OIHW form (nn.Conv2d's parameter layout) is the same sums, written transposed
+        oihw = ops.conv_wgrad(xd, 0, cin, dyd, cout, ks, stride, 1, oihw=True)
+        assert oihw.shape == (cout, cin, ks, ks) and torch.equal(oihw.cpu(), got[0].contiguous())
+
+
+@pytest.mark.parametrize("cout,cin,ks", [(64, 64, 3), (128, 64, 3), (64, 256, 1), (512, 256, 3), (32, 1024, 3)])
+def test_pack_conv_weights_equals_the_torch_permutes(cout, cin, ks):
+    from multiagentperception_amd import ops
+    w = torch.randn(cout, cin, ks, ks, generator=torch.Generator().manual_seed(cout + cin)).to(_dev())
+    fwd = ops.pack_conv_weights(w, 0)
+    assert torch.equal(fwd, w.permute(0, 2, 3, 1).reshape(1, cout, -1).to(BF16))
+    dg = ops.pack_conv_weights(w, 1)
+    assert torch.equal(dg, w.flip(2, 3).permute(1, 2, 3, 0).reshape(1, cin, -1).to(BF16))
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,hw,bias", [(64, 64, 3, 1, 16, False), (64, 128, 3, 2, 32, False), (128, 256, 1, 2, 16, False),
@@ -214,7 +227,11 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
         out = model(x) if arch == "Single_agent" else model(x, training=True, MO_flag=True)
         pred = out if arch == "Single_agent" else out[0]
         assert pred.dtype == torch.float32 and pred.shape == (b * n, 11, s, s)
-        loss = F.cross_entropy(pred, labels, ignore_index=250)               # loss/loss.py:5-18
+        if backend == "hip":
+            from multiagentperception_amd.loss import cross_entropy2d
+            loss = cross_entropy2d(input=pred, target=labels)                  # loss/loss.py:5-18 on csrc/loss.hip
+        else:
+            loss = F.cross_entropy(pred, labels, ignore_index=250)
         loss.backward()
         res[backend] = (float(loss.detach()), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None})
     train_ops.set_train_backend("hip")
@@ -253,7 +270,8 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
     # and a second HIP step from the same state is bit-identical (deterministic wgrad; MIOpen's is not)
     model.zero_grad()
     out = model(x) if arch == "Single_agent" else model(x, training=True, MO_flag=True)
-    F.cross_entropy(out if arch == "Single_agent" else out[0], labels, ignore_index=250).backward()
+    from multiagentperception_amd.loss import cross_entropy2d
+    cross_entropy2d(input=out if arch == "Single_agent" else out[0], target=labels).backward()
     mods = dict(model.named_modules())
     same = [torch.equal(p_.grad.float().cpu(), res["hip"][1][k]) for k, p_ in model.named_parameters()
             if p_.grad is not None and isinstance(mods.get(k.rsplit(".", 1)[0]), train_ops.Conv2dHip)

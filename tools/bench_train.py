@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from multiagentperception_amd import synth as filler, train_ops
+from multiagentperception_amd.loss import cross_entropy2d
 from ptsemseg.models import get_model
 
 N, B, S = [int(v) for v in (sys.argv[1:4] + ["5", "4", "512"][len(sys.argv) - 1:])]
@@ -22,7 +23,7 @@ opt = torch.optim.SGD(model.parameters(), lr=1e-5)
 def step():
     opt.zero_grad(set_to_none=True)
     pred = model(x, training=True, MO_flag=True)[0]
-    loss = F.cross_entropy(pred, labels, ignore_index=250)
+    loss = cross_entropy2d(pred, labels) if train_ops.train_backend() == "hip" else F.cross_entropy(pred, labels, ignore_index=250)
     loss.backward()
     opt.step()
     return loss

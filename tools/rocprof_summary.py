@@ -6,7 +6,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_kernel<[^>]*>|stem_kernel<\d+>|linear_kernel<[^>]*>|[A-Za-z0-9_]+_kernel\b)", name)
+    m = re.search(r"([A-Za-z0-9_]+_kernel(?:<[^>]*>)?)", name)
     if m:
         return m.group(1)
     return re.sub(r"\s+", " ", name)[:70]
