@@ -63,6 +63,7 @@ struct ConvArgs {
     const float* shift2;
     uint16_t* y2;              // bf16, groups side by side, pixel stride y2cs; no ReLU, no residual
     int y2cs;
+    int xcd2d;                 // patch kernel, 2 groups on a flattened grid: XCD -> (group, half of the tiles, half of the channel tiles)
 };
 
 // element size / channels per K-step of the two operand types: a K-step is always ONE 128-byte run per row
@@ -554,14 +555,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.y;
     const int lrow = lane >> 3, lpos = lane & 7;
 
     dbg_stamp(p, 0);
     // ---- tile decode: n fastest, then x, y, image ----
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
-    const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
-    const int tsp = tile / p.ntn, tn = tile - tsp * p.ntn;
+    int g, tsp, tn;
+    if (p.xcd2d) {
+        // weight-heavy layers (layer4: 4.7 MB of weights and 5.2 MB of input per group, 4 MB of L2 per XCD): with the tile
+        // ids dealt out contiguously every XCD streams ALL the weights of both groups.  Here XCD x (= block id mod 8) owns
+        // one group, one half of its spatial tiles and one half of its channel tiles: 2.6 + 2.35 MB per XCD instead of
+        // 1.3 + 9.4.  Placement only -- the result does not depend on it.
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int hn = p.ntn >> 1, hm = p.ntm >> 1;
+        g = xcd >> 2;
+        const int tm_l = loc / hn;
+        tn = (xcd & 1) * hn + (loc - tm_l * hn);
+        tsp = ((xcd >> 1) & 1) * hm + tm_l;
+    } else {
+        g = blockIdx.y;
+        const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
+        tsp = tile / p.ntn;
+        tn = tile - tsp * p.ntn;
+    }
     const int txi = tsp % tiles_x;
     const int tyi = (tsp / tiles_x) % tiles_y;
     const int img = tsp / (tiles_x * tiles_y);
@@ -1532,6 +1548,12 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
+    static const int xcd2d_mode = getenv("W2C_XCD2D") ? atoi(getenv("W2C_XCD2D")) : 1;
+    // weights of a group larger than half an XCD's L2 and at least as large as its input: split both operands over the XCDs
+    const long wbytes = (long)a.Cout * 9 * a.Cin * OpT<F8>::ES, xbytes = (long)a.M * a.H * a.W * a.Cin * OpT<F8>::ES;
+    a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20) && 2 * wbytes >= xbytes)) && groups == 2 && !(a.ntm & 1) &&
+              !(a.ntn & 1) && (a.ntm * a.ntn) % 4 == 0;
+    if (a.xcd2d) grid = dim3(a.ntm * a.ntn * 2, 1);
     hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
