@@ -640,6 +640,393 @@ __global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) v
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused stem, third form: the second form's arithmetic as a persistent 8-wave PING-PONG (verdict r1 item 7).
+// A workgroup is TWO groups of Cout/32 waves; wave ct of group A and wave ct of group B own the same 32 channels and sit on
+// the same SIMD.  The groups take alternate 32-column steps and run their four phases
+//     M1 (conv rows 0-4: 70 MFMAs) | V1 (BN, max, pack, pooled rows 0-1 out) | M2 (rows 5-8: 56 MFMAs) | V2 (pooled rows 2-3 out)
+// one slot apart with a workgroup barrier between slots, so in every slot one group issues the MFMAs and the other the
+// VALU / LDS / store work.  Workgroups are persistent: workgroup w walks a contiguous run of the flattened
+// (image, band, step) sequence (cfg 2: 5120 steps = 20 per CU exactly; 640 band-sized workgroups on 512 slots were 1.25
+// rounds); a run that starts inside a band first recomputes the step before it without storing it, only to obtain the
+// carried column.  Patches rotate through three LDS buffers: the group in M2(s) converts and stages patch(s+2) (fetched at
+// the top of M1(s) as 16-byte loads: 6 VMEM instructions per thread instead of 21) into the buffer the other group's
+// M2(s-1) released three slots earlier.  Pooled pixels leave as 16-byte stores straight from registers
+// (v_permlane32_swap pairs the half-waves' 4-channel quads): no LDS staging.  ReLU is one packed signed-16-bit max with 0
+// AFTER the 3x3 max.  Output is bit-identical to the other forms (tests compare all of them).
+// Measured (cfg 2, tools/bench_stem.py, tools/stem_phases.py): 100.7 us against 106.9 us for the second form.  The slots
+// do NOT shrink to the MFMA time: a wave's VALU instructions and its SIMD partner's MFMAs share the SIMD's issue, and the
+// time per pair of steps stays ~ (252 MFMAs x 32 cycles) + ~6 cycles per VALU instruction of both waves (16.2 k cycles;
+// moving 1.3 k cycles of address arithmetic and 15 VMEM issues out of M1 lengthened V1 / V2 by the same amount).  The
+// stem is bound by that sum -- 8.1 k cycles of K-padded MFMA work (147 -> 224) plus ~1.3 k VALU instructions per pair --
+// not by phase alignment; what the ping-pong form gains over the second form is the persistent, evenly divided schedule.
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b)));
+}
+
+template <bool U8>
+__global__ __launch_bounds__(512) void stem_pool3_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
+                                                         const uint16_t* __restrict__ wpk, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, uint16_t* __restrict__ y, int steps_per_wg,
+                                                         int total_steps) {
+    constexpr int COUT = 128, BAND = 8;
+    constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>();
+    constexpr int CT = COUT / 32, NT = 64 * CT;                // NT = threads per GROUP
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, ct = wave & 3;                  // waves ct and ct + 4 share a SIMD (cyclic wave -> SIMD placement)
+    const int gtid = tid & (NT - 1);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int Wo = W >> 1, Hp = H >> 2, Wp = W >> 2;
+    const int nxs = Wo >> 5, nbands = (H >> 1) / BAND;
+    char* const carry = smem + 3 * FP_BYTES + ct * 512;        // shared by the two groups' wave ct
+    char* const ssb = carry + 256;
+
+    // ---- this workgroup's run of steps ----
+    int f_begin = blockIdx.x * steps_per_wg;
+    const int f_end = min(f_begin + steps_per_wg, total_steps);
+    if (f_begin >= f_end) return;                              // (whole workgroup)
+    const bool warm = (f_begin % nxs) != 0;                    // starts inside a band: one unstored step for the carry
+    if (warm) --f_begin;
+    const int nsteps = f_end - f_begin;
+    const int my_n = grp == 0 ? (nsteps + 1) >> 1 : nsteps >> 1;
+
+    bf16x8_t wf[7][2];
+    {
+        const uint16_t* wrow = wpk + (size_t)(ct * 32 + l31) * 224;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[ky][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ky * 32 + (ks * 2 + lhi) * 8);
+        if (scale[ct * 32 + l31] < 0.f) {                      // negative BN scale: negate the weights, use |scale| (exact)
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4_t w = __builtin_bit_cast(u32x4_t, wf[ky][ks]);
+                    w ^= u32x4_t{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+                    wf[ky][ks] = __builtin_bit_cast(bf16x8_t, w);
+                }
+        }
+    }
+    if (grp == 0 && lane < 32) {
+        const int q = lane >> 3, hh = (lane >> 2) & 1, k = lane & 3;
+        reinterpret_cast<float*>(ssb)[(q * 2 + hh) * 4 + k] = fabsf(scale[ct * 32 + 8 * q + 4 * hh + k]);
+        reinterpret_cast<float*>(ssb + 128)[(q * 2 + hh) * 4 + k] = shift[ct * 32 + 8 * q + 4 * hh + k];
+    }
+    const char* const ssw = ssb + lhi * 16;
+
+    constexpr int FILL = (FP_ROWS * FP_COLS + NT - 1) / NT;
+    float pv[FILL][3];
+    unsigned pmask = 0;
+    // decode flattened step f -> image, band, column step
+    struct Step { int img, oy0, ox0; };
+    auto decode = [&](int f) {
+        Step st;
+        const int xs = f % nxs, t = f / nxs;
+        const int band = t % nbands;
+        st.img = t / nbands; st.oy0 = band * BAND; st.ox0 = xs * 32;
+        return st;
+    };
+    auto load_patch = [&](int f) {
+        const Step st = decode(f);
+        const int agent = st.img / B, b = st.img - agent * B;
+        const float* xin = U8 ? nullptr : reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
+        const uint8_t* xin8 = U8 ? reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3 : nullptr;
+#pragma unroll
+        for (int f2 = 0; f2 < FILL; ++f2) {
+            const int pidx = gtid + f2 * NT;
+            const int r = pidx / FP_COLS, c = pidx - r * FP_COLS;
+            const int iy = 2 * st.oy0 - 5 + r, ix = 2 * st.ox0 + c - 3;
+            const bool ok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+            const size_t o = ok ? (size_t)iy * W + ix : 0;
+            if constexpr (U8) {
+                pv[f2][0] = (float)xin8[o * 3 + 2]; pv[f2][1] = (float)xin8[o * 3 + 1]; pv[f2][2] = (float)xin8[o * 3];
+            } else {
+                pv[f2][0] = xin[o]; pv[f2][1] = xin[o + (size_t)H * W]; pv[f2][2] = xin[o + 2 * (size_t)H * W];
+            }
+            pmask = ok ? (pmask | (1u << f2)) : (pmask & ~(1u << f2));
+        }
+    };
+    auto store_patch = [&](uint2* patch) {
+#pragma unroll
+        for (int f2 = 0; f2 < FILL; ++f2) {
+            const int pidx = gtid + f2 * NT;
+            const bool ok = (pmask >> f2) & 1u;
+            float v0 = pv[f2][0], v1 = pv[f2][1], v2 = pv[f2][2];
+            if constexpr (U8) {
+                v0 = (float)(((double)v0 - mean.m[0]) / 255.0);
+                v1 = (float)(((double)v1 - mean.m[1]) / 255.0);
+                v2 = (float)(((double)v2 - mean.m[2]) / 255.0);
+            }
+            if (pidx < FP_ROWS * FP_COLS)
+                patch[pidx] = ok ? make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f)) : make_uint2(0u, 0u);
+        }
+    };
+    // f32 frames: the same patch fetched as 16-byte loads.  An item = 4 consecutive patch columns of one row, all three
+    // colour planes (3 x global_load_dwordx4, dword-aligned) -> 4 pixels x [c0 c1 c2 0] bf16 = two ds_write_b128.
+    // 6 VMEM instructions per thread and step instead of 21: every VMEM issue between MFMAs costs the matrix slot ~100
+    // cycles (measured: M1 4.45 k cycles for 2.24 k of MFMA with the 21 scalar loads in it).  The only items that straddle
+    // the image edge are column group 0 of a band's first step (ix = -3..0) and groups 16/17 of its last step; their load
+    // is moved inside the row and the lanes shifted at staging time (codes 1 / 2), so no load ever leaves the tensor.
+    constexpr int NI4 = FP_ROWS * (FP_COLS / 4);
+    constexpr int FILL4 = (NI4 + NT - 1) / NT;
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    f32x4_t pq[FILL4][3];
+    unsigned pm4 = 0;                                          // per item: bits 0-3 element inside the image, bits 4-5 shift code
+    bool pedge = false;                                        // (uniform) the fetched patch touches the image border
+    auto load_patch4 = [&](int f) {
+        const Step st = decode(f);
+        pedge = st.ox0 == 0 || st.ox0 + 32 >= Wo || st.oy0 == 0 || st.oy0 + BAND >= (H >> 1);
+        const int agent = st.img / B, b = st.img - agent * B;
+        const float* xin = reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
+        const int ix0 = 2 * st.ox0 - 3, iy0 = 2 * st.oy0 - 5;
+        pm4 = 0;
+#pragma unroll
+        for (int i2 = 0; i2 < FILL4; ++i2) {
+            const int it = gtid + i2 * NT;
+            const int r = it / (FP_COLS / 4), c4 = it - r * (FP_COLS / 4);
+            const int iy = iy0 + r;
+            const bool rok = (it < NI4) & ((unsigned)iy < (unsigned)H);
+            const int ixs = ix0 + 4 * c4;
+            const int ixl = min(max(ixs, 0), W - 4);
+            const int sh = ixl - ixs;
+            const unsigned o = rok ? (unsigned)(iy * W + ixl) : (unsigned)ixl;
+            pq[i2][0] = *reinterpret_cast<const f32x4_u*>(xin + o);
+            pq[i2][1] = *reinterpret_cast<const f32x4_u*>(xin + (size_t)H * W + o);
+            pq[i2][2] = *reinterpret_cast<const f32x4_u*>(xin + 2 * (size_t)H * W + o);
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m |= (rok & ((unsigned)(ixs + k) < (unsigned)W)) ? (1u << k) : 0u;
+            m |= sh == 3 ? 0x10u : (sh == -1 ? 0x20u : 0u);
+            pm4 |= m << (8 * i2);
+        }
+    };
+    auto store_patch4 = [&](uint2* patch) {
+        if (!pedge) {                                          // interior patch: nothing to mask or shift
+#pragma unroll
+            for (int i2 = 0; i2 < FILL4; ++i2) {
+                const int it = gtid + i2 * NT;
+                if (it < NI4) {
+                    uint4* d = reinterpret_cast<uint4*>(patch + it * 4);
+                    const f32x4_t a = pq[i2][0], b2 = pq[i2][1], c = pq[i2][2];
+                    d[0] = make_uint4(pack_bf16x2(a[0], b2[0]), pack_bf16x2(c[0], 0.f), pack_bf16x2(a[1], b2[1]), pack_bf16x2(c[1], 0.f));
+                    d[1] = make_uint4(pack_bf16x2(a[2], b2[2]), pack_bf16x2(c[2], 0.f), pack_bf16x2(a[3], b2[3]), pack_bf16x2(c[3], 0.f));
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < FILL4; ++i2) {
+            const int it = gtid + i2 * NT;
+            const unsigned m = pm4 >> (8 * i2);
+            const bool c1 = (m & 0x10u) != 0, c2 = (m & 0x20u) != 0;
+            uint32_t w0[4], w1[4];
+            float e[3][4];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const f32x4_t v = pq[i2][pl];
+                e[pl][0] = c2 ? v[1] : v[0];
+                e[pl][1] = c2 ? v[2] : v[1];
+                e[pl][2] = c2 ? v[3] : v[2];
+                e[pl][3] = c1 ? v[0] : v[3];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = (m >> k) & 1u;
+                w0[k] = ok ? pack_bf16x2(e[0][k], e[1][k]) : 0u;
+                w1[k] = ok ? pack_bf16x2(e[2][k], 0.f) : 0u;
+            }
+            if (it < NI4) {
+                uint4* d = reinterpret_cast<uint4*>(patch + it * 4);      // (r * 72 + 4 c4) uint2 = it * 4
+                d[0] = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+                d[1] = make_uint4(w0[2], w1[2], w0[3], w1[3]);
+            }
+        }
+    };
+    auto fetch = [&](int f) { if constexpr (U8) load_patch(f); else load_patch4(f); };
+    auto stage = [&](uint2* patch) { if constexpr (U8) store_patch(patch); else store_patch4(patch); };
+    auto slot_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slot's LDS writes are done (global loads stay in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: each group stages the patch of its first step ----
+    if (grp < nsteps) {                                        // (group B idles when the run is a single step)
+        fetch(f_begin + grp);
+        stage(reinterpret_cast<uint2*>(smem + grp * FP_BYTES));
+    }
+    slot_barrier();
+    if (grp == 1) slot_barrier();                              // group B runs one slot behind
+#ifdef W2C_STEM_TIMING
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = clock64();
+#endif
+
+    for (int j = 0; j < my_n; ++j) {
+        const int sl = grp + 2 * j;                            // local step index
+        const Step st = decode(f_begin + sl);
+        const int img = st.img, oy0 = st.oy0, ox0 = st.ox0;
+        const bool do_store = !(warm && sl == 0);
+        const uint2* patch = reinterpret_cast<const uint2*>(smem + (sl % 3) * FP_BYTES);
+        const bool nxt = sl + 2 < nsteps;
+
+        auto finish_rows = [&](int pr0, uint32_t (&pk2)[2][8]) {
+            uint4 cin[4];
+            if (l31 == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    cin[i] = ox0 == 0 ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(carry + lhi * 128 + pr0 * 32 + i * 16);
+            }
+            asm volatile("" ::: "memory");
+            if (l31 == 31) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    *reinterpret_cast<uint4*>(carry + lhi * 128 + (pr0 + pr) * 32) = make_uint4(pk2[pr][0], pk2[pr][1], pk2[pr][2], pk2[pr][3]);
+                    *reinterpret_cast<uint4*>(carry + lhi * 128 + (pr0 + pr) * 32 + 16) = make_uint4(pk2[pr][4], pk2[pr][5], pk2[pr][6], pk2[pr][7]);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    uint32_t left = lane_from_left(pk2[pr][d]);
+                    if (l31 == 0) {
+                        const uint4 c = cin[pr * 2 + (d >> 2)];
+                        left = (d & 3) == 0 ? c.x : (d & 3) == 1 ? c.y : (d & 3) == 2 ? c.z : c.w;
+                    }
+                    const uint32_t right = lane_from_right(pk2[pr][d]);
+                    // bf16 patterns ordered as SIGNED 16-bit integers: a positive beats every negative and positives order
+                    // like their values, so max-then-ReLU (one packed max with 0 per dword) equals the ReLU-then-max of the
+                    // other forms bit for bit (an all-negative window gives some negative -> 0), for half the VALU work
+                    pk2[pr][d] = pk_max_i16(pk_max_i16(pk_max_i16(left, pk2[pr][d]), right), 0u);
+                }
+            }
+            // even lanes hold pooled column l31/2: dwords (2q, 2q+1) = channels 8q + 4 lhi .. +3.  v_permlane32_swap pairs the
+            // two half-waves so that a lane ends up with 8 consecutive channels (16 B) of its pixel -- lanes 0-31 those of
+            // channel group q0, lanes 32-63 those of q0 + 1 -- and the pooled pixels go out as 16-byte stores without the
+            // LDS staging round trip (8 ds_write_b64 + 2 ds_read_b128 + two waits per pair of pooled rows: 14 us of the 103).
+            if (do_store) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int py = (oy0 >> 1) + pr0 + pr, px = (ox0 >> 1) + (l31 >> 1);
+                    uint16_t* const dst = y + (((size_t)img * Hp + py) * Wp + px) * COUT + ct * 32 + lhi * 8;
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        const auto a = __builtin_amdgcn_permlane32_swap(pk2[pr][4 * qp], pk2[pr][4 * qp + 2], false, false);
+                        const auto b = __builtin_amdgcn_permlane32_swap(pk2[pr][4 * qp + 1], pk2[pr][4 * qp + 3], false, false);
+                        if ((l31 & 1) == 0) *reinterpret_cast<uint4*>(dst + qp * 16) = make_uint4(a[0], b[0], a[1], b[1]);
+                    }
+                }
+            }
+        };
+        float keep[16];
+        auto conv_rows = [&](auto first_tag, auto count_tag, f32x16_t* acc) {
+            constexpr int R0 = decltype(first_tag)::value, RN = decltype(count_tag)::value;
+#pragma unroll
+            for (int m = 0; m < RN; ++m) {
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    const uint2* prow = patch + (2 * (R0 + m) + ky) * FP_COLS + 2 * l31 + 2 * lhi;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(prow + ks * 4);
+                        if (ky == 0 && ks == 0)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], pb, f32x16_t{0.f}, 0, 0, 0);
+                        else
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], pb, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        constexpr float NEG_INF = -3.0e38f;
+        {
+            uint32_t pk[2][8];
+            f32x16_t acc[5];
+            // ---- slot M1 ----
+            if (nxt)
+                fetch(f_begin + sl + 2);                       // consumed in M2, two slots from now
+            conv_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, acc);
+            STEM_T(0);
+            slot_barrier();
+            STEM_T(1);
+            // ---- slot V1 ----
+            const bool in0 = oy0 > 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(ssw + q * 32), sh = *reinterpret_cast<const f32x4_t*>(ssw + 128 + q * 32);
+                float v0[4], v1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * q + k;
+                    keep[e] = acc[4][e];
+                    const float m0 = fmaxf(fmaxf(in0 ? acc[0][e] : NEG_INF, acc[1][e]), acc[2][e]);
+                    const float m1 = fmaxf(fmaxf(acc[2][e], acc[3][e]), acc[4][e]);
+                    v0[k] = m0 * sc[k] + sh[k];
+                    v1[k] = m1 * sc[k] + sh[k];
+                }
+                pk[0][2 * q] = pack_bf16x2(v0[0], v0[1]);
+                pk[0][2 * q + 1] = pack_bf16x2(v0[2], v0[3]);
+                pk[1][2 * q] = pack_bf16x2(v1[0], v1[1]);
+                pk[1][2 * q + 1] = pack_bf16x2(v1[2], v1[3]);
+            }
+            finish_rows(0, pk);
+            STEM_T(2);
+            slot_barrier();
+            STEM_T(3);
+        }
+        {
+            uint32_t pk[2][8];
+            f32x16_t acc[4];
+            // ---- slot M2 (the shortest matrix slot: the patch of this group's next step is converted and staged under it;
+            // its buffer was last read by the other group's M2 three slots ago) ----
+            if (nxt)
+                stage(reinterpret_cast<uint2*>(smem + ((sl + 2) % 3) * FP_BYTES));
+            conv_rows(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, acc);
+            STEM_T(4);
+            slot_barrier();
+            STEM_T(5);
+            // ---- slot V2 ----
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(ssw + q * 32), sh = *reinterpret_cast<const f32x4_t*>(ssw + 128 + q * 32);
+                float v2[4], v3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * q + k;
+                    const float m2 = fmaxf(fmaxf(keep[e], acc[0][e]), acc[1][e]);
+                    const float m3 = fmaxf(fmaxf(acc[1][e], acc[2][e]), acc[3][e]);
+                    v2[k] = m2 * sc[k] + sh[k];
+                    v3[k] = m3 * sc[k] + sh[k];
+                }
+                pk[0][2 * q] = pack_bf16x2(v2[0], v2[1]);
+                pk[0][2 * q + 1] = pack_bf16x2(v2[2], v2[3]);
+                pk[1][2 * q] = pack_bf16x2(v3[0], v3[1]);
+                pk[1][2 * q + 1] = pack_bf16x2(v3[2], v3[3]);
+            }
+            finish_rows(2, pk);
+            STEM_T(6);
+            slot_barrier();
+            STEM_T(7);
+        }
+    }
+#ifdef W2C_STEM_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stem_phase[i], t_acc[i]);
+#endif
+    // ---- barrier parity: both groups must pass the same number of workgroup barriers ----
+    {
+        const int nA = (nsteps + 1) >> 1, nB = nsteps >> 1;
+        const int mine = grp == 0 ? 4 * nA : 1 + 4 * nB;
+        const int total_b = max(4 * nA, 1 + 4 * nB);
+        for (int i = mine; i < total_b; ++i) __builtin_amdgcn_s_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, int M, int H, int W, int C,
                                                            uint16_t* __restrict__ y) {
     const int Ho = H >> 1, Wo = W >> 1, CG = C >> 3;
@@ -742,6 +1129,31 @@ static int launch_stem_pool2(const void* x, FrameMean mean, int B, int N, int H,
     return w2c_launch_status();
 }
 
+template <bool U8>
+static int launch_stem_pool3(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
+                             const float* shift, uint16_t* y, hipStream_t s) {
+    constexpr int lds = 3 * fp_bytes<8>() + 4 * 512;
+    static unsigned long long attr_mask = 0;
+    static int n_cu[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool3_kernel<U8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        n_cu[dev & 63] = cu;
+        attr_mask |= 1ull << (dev & 63);
+    }
+    const int total = N * B * ((H / 2) / 8) * ((W / 2) / 32);
+    int wgs = n_cu[dev & 63];
+    if (const char* e = getenv("W2C_STEM_WGS")) { const int v = atoi(e); if (v > 0) wgs = v; }   // tests: odd runs, mid-band starts
+    int spw = (total + wgs - 1) / wgs;
+    if (spw < 2) spw = 2;                                      // both groups busy
+    wgs = (total + spw - 1) / spw;
+    hipLaunchKernelGGL((stem_pool3_kernel<U8>), dim3(wgs), dim3(512), lds, s, x, mean, B, N, H, W, w, scale, shift, y, spw, total);
+    return w2c_launch_status();
+}
+
 template <int COUT, bool U8>
 static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                             const float* shift, uint16_t* y, hipStream_t s) {
@@ -754,7 +1166,11 @@ static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, 
     // SIMD overlap 1.5x).  Cout = 64 (Single_agent): the LDS-pooling form is faster (95 vs 104 us).  W2C_STEM_FORM=1|2 forces.
     // Measured and dropped: a 3-waves/SIMD build (4 accumulation passes, 168 registers: 40 spilled dwords -> 186 us), 4-row
     // bands for a finer tail (1280 half-size workgroups: 112 us), staggered starts of co-resident workgroups (no change).
-    static const int form = [] { const char* e = getenv("W2C_STEM_FORM"); return e ? atoi(e) : 0; }();
+    const int form = [] { const char* e = getenv("W2C_STEM_FORM"); return e ? atoi(e) : 0; }();      // (read per launch: tests switch it)
+    // Cout = 128 default: the persistent ping-pong form (100.7 vs 106.9 us for form 2 at cfg 2)
+    if constexpr (COUT == 128) {
+        if ((form == 3 || form == 0) && H % 16 == 0) return launch_stem_pool3<U8>(x, mean, B, N, H, W, w, scale, shift, y, s);
+    }
     if ((form == 2 || (form == 0 && COUT == 128)) && H % 16 == 0)
         return launch_stem_pool2<COUT, U8>(x, mean, B, N, H, W, w, scale, shift, y, s);
     static const int nw = [] { const char* e = getenv("W2C_STEM_WAVES"); return e ? atoi(e) : 8; }();

@@ -322,6 +322,28 @@ def test_fused_stem_maxpool_equals_unfused_bit_for_bit(cout, B, N, H, W):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("wgs", [1, 3, 5, 7, 11, 48])
+def test_pingpong_stem_runs_of_any_length_and_start(wgs, monkeypatch):
+    """The persistent ping-pong stem (third form) with its workgroup count forced: runs of odd and even length, runs that start
+    inside a band (an unstored warm-up step supplies the carried column) and runs that cross bands and images."""
+    from multiagentperception_amd import ops
+    cout, B, N, H, W = 128, 1, 3, 64, 512                  # 3 images x 4 bands x 8 steps = 96 steps
+    gen = torch.Generator().manual_seed(wgs)
+    x = (torch.rand(B, 3 * N, H, W, generator=gen) - 0.45).to(_dev())
+    wp = torch.zeros(cout, 7, 8, 4)
+    wp[:, :, :7, :3] = torch.randn(cout, 7, 7, 3, generator=gen) * (2.0 / 147) ** 0.5
+    w = wp.reshape(cout, 224).to(BF16).to(_dev())
+    scale = torch.rand(cout, generator=gen) + 0.5
+    scale[::5] = -scale[::5]
+    scale = scale.to(_dev())
+    shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
+    ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
+    monkeypatch.setenv("W2C_STEM_WGS", str(wgs))
+    got = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 def test_fused_stem_is_deterministic_under_full_occupancy():
     """Both fused-stem forms at the cfg-2 shape (640 workgroups, 2 per CU for the register-pooling form: wave-private LDS
     regions, one barrier per step): 15 launches bit-identical, and the two forms equal each other."""
@@ -345,6 +367,25 @@ def test_fused_stem_is_deterministic_under_full_occupancy():
     ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
     torch.cuda.synchronize()
     assert torch.equal(first, ref)
+
+
+def test_u8_pingpong_stem_at_full_size_equals_the_f32_path():
+    """cfg-2 frames as u8 through the persistent ping-pong stem (runs of 20-21 steps that start mid-band) == the f32 path."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    B, N, S, cout = 4, 5, 512, 128
+    frames = torch.randint(0, 256, (B, N, S, S, 3), generator=gen, dtype=torch.uint8)
+    mean = torch.tensor(ops.FRAME_MEAN_BGR, dtype=torch.float64)
+    x = ((frames.flip(-1).to(torch.float64) - mean) / 255.0).to(torch.float32).permute(0, 1, 4, 2, 3).reshape(B, 3 * N, S, S).contiguous()
+    wp = torch.zeros(cout, 7, 8, 4)
+    wp[:, :, :7, :3] = torch.randn(cout, 7, 7, 3, generator=gen) * (2.0 / 147) ** 0.5
+    wd = wp.reshape(cout, 224).to(BF16).to(_dev())
+    scale = (torch.rand(cout, generator=gen) + 0.5).to(_dev())
+    shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
+    ref = ops.stem_conv7x7_bn_relu_maxpool(x.to(_dev()), N, wd, scale, shift)
+    got = ops.stem_u8_conv7x7_bn_relu_maxpool(frames.to(_dev()), wd, scale, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
 
 
 def test_maxpool_is_exact():

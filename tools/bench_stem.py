@@ -7,7 +7,8 @@ from multiagentperception_amd import ops  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    B, N, S, cout = 4, 5, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    cout = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    B, N, S = [int(v) for v in (sys.argv[2:5] + ["4", "5", "512"][len(sys.argv[2:5]):])]
     x = torch.rand(B, 3 * N, S, S, device=dev) - 0.45
     u8 = torch.randint(0, 256, (B, N, S, S, 3), dtype=torch.uint8, device=dev)
     w = (torch.randn(cout, 224, device=dev) * 0.1).to(torch.bfloat16)
@@ -27,8 +28,8 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / 50
         gf = 2.0 * N * B * (S // 2) ** 2 * cout * 147 / 1e9
-        print("stem_pool %-4s %7.1f us   %.0f TFLOP/s algorithmic (147-tap), %.0f as issued (224)" %
-              (name, us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 * 1e0 if False else gf / (us * 1e-6) / 1e3,
+        print("B=%d N=%d %dx%d stem_pool %-4s %7.1f us   %.0f TFLOP/s algorithmic (147-tap), %.0f as issued (224)" %
+              (B, N, S, S, name, us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 * 1e0 if False else gf / (us * 1e-6) / 1e3,
                gf * 224 / 147 / (us * 1e-6) / 1e3))
 
 

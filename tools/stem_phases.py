@@ -7,7 +7,7 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "tools", "libw2c_stem_phase.so")
+SO = os.environ.get("W2C_STEM_SO", os.path.join(ROOT, "tools", "libw2c_stem_phase.so"))
 
 
 def build():
@@ -31,6 +31,20 @@ def main():
     vp = ctypes.c_void_p
     lib.w2c_stem_conv7x7_bn_relu_maxpool.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                                      ctypes.c_int, vp, vp]
+    if "--time" in sys.argv:           # plain launch timing of whatever build W2C_STEM_SO names (ablation builds)
+        call = lambda: lib.w2c_stem_conv7x7_bn_relu_maxpool(x.data_ptr(), B, N, S, S, w.data_ptr(), sc.data_ptr(), sh.data_ptr(), cout,
+                                                            out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        for _ in range(5):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        print("%s: %.1f us / launch" % (os.path.basename(SO), e0.elapsed_time(e1) * 20))
+        return
     buf = (ctypes.c_ulonglong * 8)()
     lib.w2c_debug_stem_phases(None, 1)
     reps = 5
@@ -45,6 +59,9 @@ def main():
     if os.environ.get("W2C_STEM_FORM") == "2":
         names = ["store_patch", "barrier", "issue loads", "MFMA rows 0-4", "BN+vmax+pack A", "hmax+stage+store A", "MFMA rows 5-8",
                  "BN..store B"]
+    if os.environ.get("W2C_STEM_FORM", "3") in ("0", "3"):       # ping-pong form: group A's wave 0; its steps = half of all (+ warm-ups)
+        names = ["M1 (rows 0-4)", "barrier", "V1", "barrier", "M2 (rows 5-8)", "barrier", "V2 + patch store", "barrier"]
+        steps = steps / 2
     tot = 0
     for n, v in zip(names, buf):
         print("%-16s %8.0f cycles / workgroup-step" % (n, v / steps))
