@@ -718,10 +718,15 @@ __global__ __launch_bounds__(512) void stem_pool3_kernel(const void* __restrict_
         reinterpret_cast<float*>(ssb + 128)[(q * 2 + hh) * 4 + k] = shift[ct * 32 + 8 * q + 4 * hh + k];
     }
     const char* const ssw = ssb + lhi * 16;
+    if constexpr (U8) {                                        // loader transform table: [c = B, G, R][256] bf16
+        uint16_t* const lw = reinterpret_cast<uint16_t*>(smem + 3 * FP_BYTES + 4 * 512);
+        for (int e = tid; e < 768; e += 512) {
+            const int c = e >> 8, v = e & 255;
+            lw[e] = f32_to_bf16((float)(((double)v - mean.m[c]) / 255.0));
+        }
+        __syncthreads();                                       // the prologue stages a patch through the table
+    }
 
-    constexpr int FILL = (FP_ROWS * FP_COLS + NT - 1) / NT;
-    float pv[FILL][3];
-    unsigned pmask = 0;
     // decode flattened step f -> image, band, column step
     struct Step { int img, oy0, ox0; };
     auto decode = [&](int f) {
@@ -730,41 +735,6 @@ __global__ __launch_bounds__(512) void stem_pool3_kernel(const void* __restrict_
         const int band = t % nbands;
         st.img = t / nbands; st.oy0 = band * BAND; st.ox0 = xs * 32;
         return st;
-    };
-    auto load_patch = [&](int f) {
-        const Step st = decode(f);
-        const int agent = st.img / B, b = st.img - agent * B;
-        const float* xin = U8 ? nullptr : reinterpret_cast<const float*>(xv) + ((size_t)b * 3 * N + 3 * agent) * H * W;
-        const uint8_t* xin8 = U8 ? reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3 : nullptr;
-#pragma unroll
-        for (int f2 = 0; f2 < FILL; ++f2) {
-            const int pidx = gtid + f2 * NT;
-            const int r = pidx / FP_COLS, c = pidx - r * FP_COLS;
-            const int iy = 2 * st.oy0 - 5 + r, ix = 2 * st.ox0 + c - 3;
-            const bool ok = (pidx < FP_ROWS * FP_COLS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
-            const size_t o = ok ? (size_t)iy * W + ix : 0;
-            if constexpr (U8) {
-                pv[f2][0] = (float)xin8[o * 3 + 2]; pv[f2][1] = (float)xin8[o * 3 + 1]; pv[f2][2] = (float)xin8[o * 3];
-            } else {
-                pv[f2][0] = xin[o]; pv[f2][1] = xin[o + (size_t)H * W]; pv[f2][2] = xin[o + 2 * (size_t)H * W];
-            }
-            pmask = ok ? (pmask | (1u << f2)) : (pmask & ~(1u << f2));
-        }
-    };
-    auto store_patch = [&](uint2* patch) {
-#pragma unroll
-        for (int f2 = 0; f2 < FILL; ++f2) {
-            const int pidx = gtid + f2 * NT;
-            const bool ok = (pmask >> f2) & 1u;
-            float v0 = pv[f2][0], v1 = pv[f2][1], v2 = pv[f2][2];
-            if constexpr (U8) {
-                v0 = (float)(((double)v0 - mean.m[0]) / 255.0);
-                v1 = (float)(((double)v1 - mean.m[1]) / 255.0);
-                v2 = (float)(((double)v2 - mean.m[2]) / 255.0);
-            }
-            if (pidx < FP_ROWS * FP_COLS)
-                patch[pidx] = ok ? make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f)) : make_uint2(0u, 0u);
-        }
     };
     // f32 frames: the same patch fetched as 16-byte loads.  An item = 4 consecutive patch columns of one row, all three
     // colour planes (3 x global_load_dwordx4, dword-aligned) -> 4 pixels x [c0 c1 c2 0] bf16 = two ds_write_b128.
@@ -847,8 +817,74 @@ __global__ __launch_bounds__(512) void stem_pool3_kernel(const void* __restrict_
             }
         }
     };
-    auto fetch = [&](int f) { if constexpr (U8) load_patch(f); else load_patch4(f); };
-    auto stage = [&](uint2* patch) { if constexpr (U8) store_patch(patch); else store_patch4(patch); };
+    // u8 camera frames ([B][N][H][W][3] RGB): an item's 4 pixels are 12 consecutive bytes; with W % 64 == 0 they always sit at
+    // byte 3 of a dword-aligned 16-byte window -> ONE global_load_dwordx4 per item (2 per thread-step; the per-byte form issued
+    // 21), and the loader's transform (airsim_loader.py:521-527: RGB -> BGR, float64 (v - mean) / 255, f32) comes from a
+    // 3 x 256-entry bf16 table in LDS built at kernel start with exactly that arithmetic (bit-identical), not from ~15 f64
+    // instructions per element.  Edge items: the window is moved inside the row, b0 = byte of pixel 0 inside it (3 normally,
+    // -9 for the left-edge item whose only valid pixel is its last, 7 for the right-edge item).
+    const uint16_t* const lut = reinterpret_cast<const uint16_t*>(smem + 3 * FP_BYTES + 4 * 512);
+    u32x4_t pw8[FILL4];
+    auto load_patch8 = [&](int f) {
+        const Step st = decode(f);
+        const int agent = st.img / B, b = st.img - agent * B;
+        const uint8_t* xin8 = reinterpret_cast<const uint8_t*>(xv) + ((size_t)b * N + agent) * H * W * 3;
+        const int ix0 = 2 * st.ox0 - 3, iy0 = 2 * st.oy0 - 5;
+        pedge = st.ox0 == 0 || st.ox0 + 32 >= Wo || st.oy0 == 0 || st.oy0 + BAND >= (H >> 1);
+        pm4 = 0;
+#pragma unroll
+        for (int i2 = 0; i2 < FILL4; ++i2) {
+            const int it = gtid + i2 * NT;
+            const int r = it / (FP_COLS / 4), c4 = it - r * (FP_COLS / 4);
+            const int iy = iy0 + r;
+            const bool rok = (it < NI4) & ((unsigned)iy < (unsigned)H);
+            const int ixs = ix0 + 4 * c4;
+            const int win = min(max(3 * ixs - 3, 0), 3 * W - 16);
+            const int b0 = 3 * ixs - win;
+            const unsigned o = (rok ? (unsigned)(iy * W * 3) : 0u) + (unsigned)win;
+            pw8[i2] = *reinterpret_cast<const u32x4_t*>(xin8 + o);
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m |= (rok & ((unsigned)(ixs + k) < (unsigned)W)) ? (1u << k) : 0u;
+            m |= b0 == -9 ? 0x10u : (b0 == 7 ? 0x20u : 0u);
+            pm4 |= m << (8 * i2);
+        }
+    };
+    auto store_patch8 = [&](uint2* patch) {
+#pragma unroll
+        for (int i2 = 0; i2 < FILL4; ++i2) {
+            const int it = gtid + i2 * NT;
+            const u32x4_t d = pw8[i2];
+            // pixel k = bytes 3 + 3k .. of the window (R, G, B in the low three bytes of px[k])
+            uint32_t px[4] = {__builtin_amdgcn_alignbyte(d[1], d[0], 3), __builtin_amdgcn_alignbyte(d[2], d[1], 2),
+                              __builtin_amdgcn_alignbyte(d[3], d[2], 1), d[3]};
+            unsigned m = 0xFu;
+            if (pedge) {
+                m = pm4 >> (8 * i2);
+                if (m & 0x10u) px[3] = d[0];                                      // left edge: pixel 3 = bytes 0..2
+                if (m & 0x20u) {                                                  // right edge: pixels 0..2 = bytes 7, 10, 13
+                    px[0] = __builtin_amdgcn_alignbyte(d[2], d[1], 3);
+                    px[1] = __builtin_amdgcn_alignbyte(d[3], d[2], 2);
+                    px[2] = d[3] >> 8;
+                }
+            }
+            uint32_t w0[4], w1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t rr = px[k] & 255u, gg = (px[k] >> 8) & 255u, bb = (px[k] >> 16) & 255u;
+                const bool ok = (m >> k) & 1u;
+                w0[k] = ok ? ((uint32_t)lut[bb] | ((uint32_t)lut[256 + gg] << 16)) : 0u;
+                w1[k] = ok ? (uint32_t)lut[512 + rr] : 0u;
+            }
+            if (it < NI4) {
+                uint4* dd = reinterpret_cast<uint4*>(patch + it * 4);
+                dd[0] = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+                dd[1] = make_uint4(w0[2], w1[2], w0[3], w1[3]);
+            }
+        }
+    };
+    auto fetch = [&](int f) { if constexpr (U8) load_patch8(f); else load_patch4(f); };
+    auto stage = [&](uint2* patch) { if constexpr (U8) store_patch8(patch); else store_patch4(patch); };
     auto slot_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slot's LDS writes are done (global loads stay in flight)
         __builtin_amdgcn_s_barrier();
@@ -1132,7 +1168,7 @@ static int launch_stem_pool2(const void* x, FrameMean mean, int B, int N, int H,
 template <bool U8>
 static int launch_stem_pool3(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                              const float* shift, uint16_t* y, hipStream_t s) {
-    constexpr int lds = 3 * fp_bytes<8>() + 4 * 512;
+    constexpr int lds = 3 * fp_bytes<8>() + 4 * 512 + (U8 ? 1536 : 0);
     static unsigned long long attr_mask = 0;
     static int n_cu[64] = {0};
     int dev = 0;
