@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
 // pixels with 0 <= gt < n) fused behind the argmax -- each workgroup histograms its 32-row band in LDS (a wave whose 64
 // lanes all hit one bin, the common case inside a segment, adds 64 with one atomic) and flushes its non-zero bins
 // with one 64-bit global atomic each.  Integer atomics: the result is exact and order-independent.
+constexpr int ARG_ROWS = 8;
 template <bool CONF, bool GT64>
 __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
                                                                 uint8_t* __restrict__ labels, const void* __restrict__ gt,
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
         for (int i = threadIdx.x; i < ncls * ncls; i += 256) lh[i] = 0;
     }
     const int H = h * 32, W = w * 32;
+    // a workgroup = ARG_ROWS output rows of one image (32-row bands were 320 workgroups at cfg 2: 1.25 per CU, 4 waves per
+    // CU -- the kernel idled on latency: 46 us for 5 MB of output)
     const int band = blockIdx.x, m = blockIdx.y;
     for (int i = threadIdx.x; i < ncls * h * w; i += 256) {
         const int c = i / (h * w), p = i - c * (h * w);
@@ -80,10 +83,10 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
     }
     __syncthreads();
     const int xq = W >> 2;
-    uint8_t* obase = labels + ((size_t)m * H + (size_t)band * 32) * W;
-    for (int id = threadIdx.x; id < 32 * xq; id += 256) {
+    uint8_t* obase = labels + ((size_t)m * H + (size_t)band * ARG_ROWS) * W;
+    for (int id = threadIdx.x; id < ARG_ROWS * xq; id += 256) {
         const int ry = id / xq, gx = id - ry * xq;
-        const int oy = band * 32 + ry;
+        const int oy = band * ARG_ROWS + ry;
         float sy = (oy + 0.5f) * 0.03125f - 0.5f;
         sy = sy < 0.f ? 0.f : sy;
         const int y0 = (int)sy;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
         const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
         if (labels) *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W + gx * 4) = packed;
         if (CONF) {
-            const size_t pix = ((size_t)m * H + (size_t)band * 32 + ry) * W + gx * 4;
+            const size_t pix = ((size_t)m * H + (size_t)band * ARG_ROWS + ry) * W + gx * 4;
             long long g4[4];
             if (GT64) {
                 const long long* gp = reinterpret_cast<const long long*>(gt) + pix;
@@ -274,7 +277,7 @@ extern "C" int w2c_upsample32_argmax(const float* low, int M, int h, int w, int 
         return W2C_E_ARG;
     const size_t lds = (size_t)n_classes * h * w * 4;
     if (lds > 64 * 1024) return W2C_E_ARG;
-    hipLaunchKernelGGL((upsample32_argmax_kernel<false, false>), dim3(h, M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL((upsample32_argmax_kernel<false, false>), dim3(h * (32 / ARG_ROWS), M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        low, h, w, low_cstride, n_classes, labels, nullptr, nullptr);
     return w2c_launch_status();
 }
@@ -291,10 +294,10 @@ extern "C" int w2c_upsample32_argmax_confusion(const float* low, int M, int h, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned long long* hp = reinterpret_cast<unsigned long long*>(hist);
     if (gt_is_i64)
-        hipLaunchKernelGGL((upsample32_argmax_kernel<true, true>), dim3(h, M), dim3(256), lds, s, low, h, w, low_cstride,
+        hipLaunchKernelGGL((upsample32_argmax_kernel<true, true>), dim3(h * (32 / ARG_ROWS), M), dim3(256), lds, s, low, h, w, low_cstride,
                            n_classes, labels, gt, hp);
     else
-        hipLaunchKernelGGL((upsample32_argmax_kernel<true, false>), dim3(h, M), dim3(256), lds, s, low, h, w, low_cstride,
+        hipLaunchKernelGGL((upsample32_argmax_kernel<true, false>), dim3(h * (32 / ARG_ROWS), M), dim3(256), lds, s, low, h, w, low_cstride,
                            n_classes, labels, gt, hp);
     return w2c_launch_status();
 }
