@@ -77,16 +77,17 @@ def cross_entropy2d(input, target, weight=None, size_average=True):
 
 
 def multi_scale_cross_entropy2d(input, target, weight=None, size_average=True, scale_weight=None):
-    """loss.py:21-38: auxiliary-head weighting (1, 0.4, 0.16, ...) when the model returns a tuple."""
+    """loss.py:21-38: a model with auxiliary heads returns a tuple of logits; head i is weighted 0.4**i unless the caller
+    passes `scale_weight`.  A single tensor is the plain cross entropy."""
     if not isinstance(input, tuple):
         return cross_entropy2d(input=input, target=target, weight=weight, size_average=size_average)
-    if scale_weight is None:
-        n_inp = len(input)
-        scale_weight = torch.pow(0.4 * torch.ones(n_inp), torch.arange(n_inp).float()).to(target.device)
-    loss = 0.0
-    for i, inp in enumerate(input):
-        loss = loss + scale_weight[i] * cross_entropy2d(input=inp, target=target, weight=weight, size_average=size_average)
-    return loss
+    terms = [cross_entropy2d(input=head, target=target, weight=weight, size_average=size_average) for head in input]
+    if scale_weight is None:            # f32 powers of f32 0.4, as the reference builds them
+        scale_weight = torch.pow(torch.full((len(terms),), 0.4), torch.arange(len(terms)).float()).to(target.device)
+    total = 0.0
+    for w, t in zip(scale_weight, terms):
+        total = total + w * t
+    return total
 
 
 def bootstrapped_cross_entropy2d(input, target, K, weight=None, size_average=True):
@@ -109,14 +110,15 @@ key2loss = {
 
 
 def get_loss_function(cfg):
-    """ptsemseg/loss/__init__.py:22-37."""
-    if cfg["training"]["loss"] is None:
+    """ptsemseg/loss/__init__.py:22-37: `training.loss` of the yml is None (plain cross entropy) or a dict whose `name` picks
+    the function and whose other keys are bound as keyword arguments."""
+    spec = cfg["training"]["loss"]
+    if spec is None:
         logger.info("Using default cross entropy loss")
         return cross_entropy2d
-    loss_dict = cfg["training"]["loss"]
-    loss_name = loss_dict["name"]
-    loss_params = {k: v for k, v in loss_dict.items() if k != "name"}
-    if loss_name not in key2loss:
-        raise NotImplementedError("Loss {} not implemented".format(loss_name))
-    logger.info("Using {} with {} params".format(loss_name, loss_params))
-    return functools.partial(key2loss[loss_name], **loss_params)
+    kwargs = dict(spec)
+    name = kwargs.pop("name")
+    if name not in key2loss:
+        raise NotImplementedError("Loss {} not implemented".format(name))
+    logger.info("Using %s with %s params", name, kwargs)
+    return functools.partial(key2loss[name], **kwargs)
