@@ -1548,7 +1548,8 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    static const int xcd2d_mode = getenv("W2C_XCD2D") ? atoi(getenv("W2C_XCD2D")) : 1;
+    const char* const xe = getenv("W2C_XCD2D");                 // (read per launch: tests and tools/ab_xcd2d.sh switch it)
+    const int xcd2d_mode = xe ? atoi(xe) : 1;
     // weights of a group larger than half an XCD's L2 and at least as large as its input: split both operands over the XCDs
     const long wbytes = (long)a.Cout * 9 * a.Cin * OpT<F8>::ES, xbytes = (long)a.M * a.H * a.W * a.Cin * OpT<F8>::ES;
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20) && 2 * wbytes >= xbytes)) && groups == 2 && !(a.ntm & 1) &&

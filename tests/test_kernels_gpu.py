@@ -278,6 +278,29 @@ def test_conv_result_is_independent_of_tile_variant_and_image_count(cin, cout, h
         assert torch.equal(part, full_s[lo:lo + n])
 
 
+@pytest.mark.parametrize("cin,cout,hw,M", [(512, 512, 16, 20), (256, 256, 16, 6), (128, 128, 32, 2)])
+def test_xcd_tile_placement_does_not_change_results(cin, cout, hw, M, monkeypatch):
+    """Two-group patch launches place their tiles per XCD (group, half the spatial tiles, half the channel tiles) when the
+    weights dominate; placement is speed only: forced off (0), heuristic (1) and forced on (2) give identical bits."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(cin + hw + M)
+    G = 2
+    x = torch.randn(M, hw, hw, G * cin, generator=gen).to(BF16).to(_dev())
+    w = (torch.randn(G, cout, 9 * cin, generator=gen) * (2.0 / (9 * cin)) ** 0.5).to(BF16).to(_dev())
+    sc = (torch.rand(G * cout, generator=gen) + 0.5).to(_dev())
+    sh = (torch.randn(G * cout, generator=gen) * 0.1).to(_dev())
+    res = torch.randn(M, hw, hw, G * cout, generator=gen).to(BF16).to(_dev())
+    outs = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("W2C_XCD2D", mode)
+        for v in (30, 36):
+            outs[(mode, v)] = ops.conv_igemm(x, 0, cin, w, cout, 3, 1, G, sc, sh, residual=res, variant=v)
+    torch.cuda.synchronize()
+    ref = outs[("0", 36)]
+    for k, y in outs.items():
+        assert torch.equal(y, ref), k
+
+
 @pytest.mark.parametrize("cout,B,N,H,W", [(64, 2, 1, 64, 64), (128, 2, 3, 64, 128), (128, 1, 2, 128, 128)])
 def test_stem_matches_fp32_conv7x7_bn_relu(cout, B, N, H, W):
     from multiagentperception_amd import ops
