@@ -11,9 +11,10 @@ squeezers, policy conv1..5, the decoder's first conv: 97 % of the training FLOPs
   dW        w2c_conv_wgrad_bf16 (MFMA over pixels via transposed LDS reads, deterministic)
   dbias     a column sum
 
-Activations travel as bf16 NHWC (torch ``channels_last``), master weights stay f32 (a mixed-precision step).  The 7x7 stem
-(Cin = 3) and the decoder's 256 -> 11 head (Cout = 11) are outside the kernels' shape rules and are ASSIGNED to the stock
-convolution -- a documented scope line, not a fallback: a supported conv on a GPU tensor raises if the library is missing.
+Activations travel as bf16 NHWC (torch ``channels_last``), master weights stay f32 (a mixed-precision step).  The decoder's
+256 -> 11 head runs on the same kernels with its filters zero-padded to 64 (autograd slices the gradients back).  The 7x7 stem
+(Cin = 3) is outside the kernels' shape rules and is ASSIGNED to the stock convolution -- a documented scope line, not a
+fallback: a supported conv on a GPU tensor raises if the library is missing.
 ``set_train_backend("stock")`` (or W2C_TRAIN_BACKEND=stock) runs everything on stock ops, e.g. as the gradient oracle in
 tests/test_train_gpu.py.
 """
@@ -115,10 +116,20 @@ class _Conv2dHipFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def hip_supported(conv):
+def _hip_geometry(conv):
     k, s = conv.kernel_size, conv.stride
     return (k[0] == k[1] and k[0] in (1, 3) and s[0] == s[1] and s[0] in (1, 2) and conv.padding == (k[0] // 2, k[0] // 2)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0)
+
+
+def hip_supported(conv):
+    return _hip_geometry(conv) and conv.out_channels % 64 == 0
+
+
+def hip_supported_padded(conv):
+    """a conv whose only obstacle is an output width that is not a multiple of 64 (the decoder's 256 -> 11 head): it runs on the
+    same kernels with zero filters appended up to the next multiple of 64; autograd slices the gradients back."""
+    return _hip_geometry(conv) and conv.out_channels % 64 != 0
 
 
 class Conv2dHip(nn.Conv2d):
@@ -126,8 +137,14 @@ class Conv2dHip(nn.Conv2d):
     backend is "hip", the input is on the GPU and the shape is one the kernels cover; see the module docstring."""
 
     def forward(self, x):
-        if _backend == "hip" and x.is_cuda and hip_supported(self) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
-            return _Conv2dHipFn.apply(x, self.weight, self.bias, self.stride[0])
+        if _backend == "hip" and x.is_cuda and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            if hip_supported(self):
+                return _Conv2dHipFn.apply(x, self.weight, self.bias, self.stride[0])
+            if hip_supported_padded(self):
+                pad = -self.out_channels % 64
+                w = F.pad(self.weight, (0, 0, 0, 0, 0, 0, 0, pad))
+                b = None if self.bias is None else F.pad(self.bias, (0, pad))
+                return _Conv2dHipFn.apply(x, w, b, self.stride[0])[:, :self.out_channels]
         if x.dtype != self.weight.dtype:            # bf16 activations meet f32 master weights in the two stock convs
             return F.conv2d(x, self.weight.to(x.dtype), None if self.bias is None else self.bias.to(x.dtype), self.stride,
                             self.padding, self.dilation, self.groups)

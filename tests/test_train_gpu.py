@@ -64,7 +64,9 @@ def test_pack_conv_weights_equals_the_torch_permutes(cout, cin, ks):
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,hw,bias", [(64, 64, 3, 1, 16, False), (64, 128, 3, 2, 32, False), (128, 256, 1, 2, 16, False),
-                                                        (512, 256, 3, 1, 8, True), (256, 256, 3, 2, 8, True)])
+                                                        (512, 256, 3, 1, 8, True), (256, 256, 3, 2, 8, True),
+                                                        (256, 11, 3, 1, 16, True),        # decoder head: filters zero-padded to 64
+                                                        (64, 96, 1, 1, 8, False)])
 def test_conv2d_hip_function_gradients_match_stock_conv(cin, cout, ks, stride, hw, bias):
     """train_ops.Conv2dHip (forward + dX + dW + dbias on the HIP kernels) vs the same nn.Conv2d on stock ops in f32."""
     from multiagentperception_amd import train_ops
