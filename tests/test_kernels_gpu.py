@@ -709,3 +709,46 @@ def test_stride2_block_front_in_one_launch_equals_the_two_convs(cin, cout, hw, M
     t, t8, idt = ops.conv_s2_block(x, 64, cin, w3, sc3, sh3, w1, sc1, sh1, cout, G, t_bf16=False, t_fp8_scale=0.03)
     _, t8_ref = ops.conv_fp8(x, 64, cin, w3, cout, 3, 2, G, sc3, sh3, relu=True, out_bf16=False, out_fp8_scale=0.03)
     assert t is None and torch.equal(t8, t8_ref) and torch.equal(idt, i_ref)
+
+
+@pytest.mark.parametrize("variant,cin,cout,hw", [(60, 64, 128, 128), (60, 256, 512, 32), (62, 128, 256, 64), (61, 128, 256, 64)])
+def test_stride2_patch_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
+    """The polyphase stride-2 kernel rotates two patch buffers across four phases per chunk under counted vmcnt waits: a
+    full-chip launch (cfg-2 shapes, M = 20, two groups) repeated 20 times must be bit-identical every time, alone and with
+    the fused 1x1 downsample, and equal to the generic kernel."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(variant + cin)
+    M, G = 20, 2
+    x = torch.randn(M, hw, hw, G * cin, generator=gen).to(BF16).to(_dev())
+    w3 = (torch.randn(G, cout, 9 * cin, generator=gen) * (2.0 / (9 * cin)) ** 0.5).to(BF16).to(_dev())
+    w1 = (torch.randn(G, cout, cin, generator=gen) * (2.0 / cin) ** 0.5).to(BF16).to(_dev())
+    sc = (torch.rand(G * cout, generator=gen) + 0.5).to(_dev())
+    sh = (torch.randn(G * cout, generator=gen) * 0.1).to(_dev())
+    ref = ops.conv_igemm(x, 0, cin, w3, cout, 3, 2, G, sc, sh, variant=3)
+    iref = ops.conv_igemm(x, 0, cin, w1, cout, 1, 2, G, sc, sh, relu=False)
+    for _ in range(20):
+        y = ops.conv_igemm(x, 0, cin, w3, cout, 3, 2, G, sc, sh, variant=variant)
+        t, _, idt = ops.conv_s2_block(x, 0, cin, w3, sc, sh, w1, sc, sh, cout, G, variant=variant)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref) and torch.equal(t, ref) and torch.equal(idt, iref)
+
+
+@pytest.mark.parametrize("wgs", [64, 256, 300])
+def test_pingpong_stem_is_race_free_over_repeated_launches(wgs, monkeypatch):
+    """Persistent ping-pong stem at a 4-image 512x512 batch with 64 / 256 / 300 workgroups (runs of 16, 4 and 3-4 steps; three
+    rotating patch buffers, barrier-separated slots): 12 launches each, all bit-identical to the unfused reference."""
+    from multiagentperception_amd import ops
+    cout, B, N, S = 128, 2, 2, 512
+    gen = torch.Generator().manual_seed(wgs)
+    x = (torch.rand(B, 3 * N, S, S, generator=gen) - 0.45).to(_dev())
+    wp = torch.zeros(cout, 7, 8, 4)
+    wp[:, :, :7, :3] = torch.randn(cout, 7, 7, 3, generator=gen) * (2.0 / 147) ** 0.5
+    w = wp.reshape(cout, 224).to(BF16).to(_dev())
+    scale = (torch.rand(cout, generator=gen) + 0.5).to(_dev())
+    shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
+    ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
+    monkeypatch.setenv("W2C_STEM_WGS", str(wgs))
+    for _ in range(12):
+        got = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
