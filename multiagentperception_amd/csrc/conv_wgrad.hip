@@ -13,6 +13,7 @@
 // tap (double-buffered); 9 accumulator sets per wave.  Segments' partial tiles go to a workspace and are summed in segment
 // order by a second launch (deterministic -- no float atomics).
 #include "w2c_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -160,22 +161,170 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #endif
 }
 
+// 3x3 / stride-1 form on HALO PATCHES (the forward patch kernel's idea): a block is an 8 x 16 spatial tile of one image; its
+// (8+2) x (16+2) input patch is staged ONCE (23 LDS-DMA instructions per workgroup) and all 9 taps read their transposed
+// fragments from it at a shifted pixel index -- the generic form above re-stages a 128-pixel X tile per tap (9 x 16
+// instructions, and a vmcnt(0) + barrier per tap that exposes the DMA latency nine times per block).  Patch + dY tile are
+// double-buffered across blocks: one barrier per block, 72 MFMAs per wave between barriers.  78 KB of LDS: two workgroups per
+// CU.  Same partial-tile / segment / reduction contract as conv_wgrad_kernel (the pixel order inside a segment differs, so the
+// two forms round differently; each is deterministic).
+__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 8, TW = 16, PW = TW + 2, NP = (TH + 2) * PW;          // 180 patch pixels
+    constexpr int NPI = (NP + 7) / 8;                                          // 23 DMA instructions (8 pixel rows each)
+    constexpr int PATCH_B = NPI * 1024, Y_B = TH * TW * 128, BUF_B = PATCH_B + Y_B;
+    constexpr int PJ = (NPI + 3) / 4;                                          // patch instructions per wave (last: waves 0-2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];               // [2][patch | dY tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = blockIdx.z, seg = blockIdx.y;
+    const int to = blockIdx.x / p.nct_i, ti = blockIdx.x - to * p.nct_i;
+    const int lrow = lane >> 3, lpos = lane & 7;
+
+    const char* xg = reinterpret_cast<const char*>(p.x) + ((size_t)g * p.Cin + ti * 64) * 2;
+    const char* yg = reinterpret_cast<const char*>(p.dy) + ((size_t)g * p.Cout + to * 64) * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(yg), 0, (int)((size_t)p.rows * p.ycs * 2), 0x00020000);
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH;
+    const int nblocks = p.M * tiles_x * tiles_y;
+    const int b_begin = seg * p.blocks_per_seg;
+    const int b_end = min(nblocks, b_begin + p.blocks_per_seg);
+    // this lane's fixed positions: patch pixel of DMA instruction j, tile pixel of dY instruction j
+    int ppy[PJ], ppx[PJ], psrc[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int q = (wave + 4 * j) * 8 + lrow;
+        ppy[j] = q / PW; ppx[j] = q - ppy[j] * PW;
+        psrc[j] = q < NP ? ((((lpos >> 1) ^ wg_swz(q)) << 1) | (lpos & 1)) * 16 : -1;
+    }
+    int yty[4], ytx[4], ysrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rloc = (wave + 4 * j) * 8 + lrow;
+        yty[j] = rloc / TW; ytx[j] = rloc - yty[j] * TW;
+        ysrc[j] = ((((lpos >> 1) ^ wg_swz(rloc)) << 1) | (lpos & 1)) * 16;
+    }
+    auto issue = [&](int blk, int buf) {
+        const int txi = blk % tiles_x, t2 = blk / tiles_x;
+        const int tyi = t2 % tiles_y, img = t2 / tiles_y;
+        const int y0 = tyi * TH, x0 = txi * TW;
+        char* pd = smem + buf * BUF_B;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            if (wave + 4 * j < NPI) {                                        // wave-uniform
+                const int iy = y0 - 1 + ppy[j], ix = x0 - 1 + ppx[j];
+                const bool ok = (psrc[j] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned vo = ok ? (unsigned)((((long)img * p.H + iy) * p.W + ix) * p.xcs * 2 + psrc[j]) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(pd + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned vo = (unsigned)((((long)img * p.Ho + y0 + yty[j]) * p.Wo + x0 + ytx[j]) * p.ycs * 2 + ysrc[j]);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, W2C_LPTR(pd + PATCH_B + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+    if (b_begin < b_end) issue(b_begin, 0);
+    int buf = 0;
+    for (int blk = b_begin; blk < b_end; ++blk, buf ^= 1) {
+        wg_wait_vmcnt<0>();
+        __syncthreads();                     // block `blk` landed for everyone; everyone is done reading the other buffer
+        if (blk + 1 < b_end) issue(blk + 1, buf ^ 1);
+        const char* patch = smem + buf * BUF_B;
+        const char* Ys = patch + PATCH_B;
+        bf16x8_t ya[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ya[kk] = tr_frag(Ys, kk * 16, wm * 32, lane);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {                                  // tile row kk = 16 consecutive patch pixels
+                const bf16x8_t xb = tr_frag(patch, (kk + ky) * PW + kx, wn * 32, lane);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[kk], xb, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const size_t wsz = (size_t)gridDim.z * p.Cout * 9 * p.Cin;
+    float* out = p.ws + (size_t)seg * wsz + ((size_t)g * p.Cout + to * 64 + wm * 32) * 9 * p.Cin + ti * 64 + wn * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            out[((size_t)co * 9 + tap) * p.Cin] = acc[tap][e];
+        }
+#endif
+}
+
+// Sum of the nseg partial tiles, 4 consecutive floats per column index i.  SL = 1: one thread walks the segments of its
+// column (fine for the handful of segments of the wide layers).  SL = 16: layer1-type convs have ONE 64x64 tile and ~400
+// segments -- 9 216 columns x 435 dependent loads ran at 0.6 TB/s (109 us for 64 MB, 2.5x the MFMA kernel); here 16 threads
+// share a column (segments sl, sl+16, ...: independent loads, 4 in flight each), combined through LDS in lane order.
+// Either way the order of additions is fixed by (nseg, SL): deterministic.
+template <int SL>
+__device__ __forceinline__ bool wgrad_seg_sum(const float* __restrict__ ws, long n4, int nseg, long& i, f32x4_t& s) {
+    if constexpr (SL == 1) {
+        i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n4) return false;
+        s = reinterpret_cast<const f32x4_t*>(ws)[i];
+        for (int k = 1; k < nseg; ++k) s += reinterpret_cast<const f32x4_t*>(ws)[(size_t)k * n4 + i];
+        return true;
+    } else {
+        constexpr int COLS = 256 / SL;
+        __shared__ f32x4_t red[SL][COLS];
+        const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+        i = (long)blockIdx.x * COLS + col;
+        const bool in = i < n4;
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        if (in) {
+            const f32x4_t* base = reinterpret_cast<const f32x4_t*>(ws) + i;
+            int k = sl;
+            for (; k + 3 * SL < nseg; k += 4 * SL) {
+                a0 += base[(size_t)k * n4];
+                a1 += base[(size_t)(k + SL) * n4];
+                a2 += base[(size_t)(k + 2 * SL) * n4];
+                a3 += base[(size_t)(k + 3 * SL) * n4];
+            }
+            for (; k < nseg; k += SL) a0 += base[(size_t)k * n4];
+        }
+        red[sl][col] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (sl != 0 || !in) return false;
+        s = red[0][col];
+#pragma unroll
+        for (int j = 1; j < SL; ++j) s += red[j][col];
+        return true;
+    }
+}
+
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int nseg) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4_t s = reinterpret_cast<const f32x4_t*>(ws)[i];
-    for (int k = 1; k < nseg; ++k) s += reinterpret_cast<const f32x4_t*>(ws)[(size_t)k * n4 + i];
+    long i;
+    f32x4_t s;
+    if (!wgrad_seg_sum<SL>(ws, n4, nseg, i, s)) return;
     reinterpret_cast<f32x4_t*>(dw)[i] = s;
 }
 
 // the same reduction, written in nn.Conv2d's parameter layout [Cout][Cin][ky][kx] (groups = 1) so that the optimiser reads the
 // gradient where autograd expects it, with no permute copy in between.  i indexes 4 consecutive ci of one (co, tap).
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_oihw_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int nseg,
                                                                  int taps, int cin) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4_t s = reinterpret_cast<const f32x4_t*>(ws)[i];
-    for (int k = 1; k < nseg; ++k) s += reinterpret_cast<const f32x4_t*>(ws)[(size_t)k * n4 + i];
+    long i;
+    f32x4_t s;
+    if (!wgrad_seg_sum<SL>(ws, n4, nseg, i, s)) return;
     const long e = i * 4;                          // = (co * taps + tap) * cin + ci
     const int ci = (int)(e % cin);
     const long ct = e / cin;
@@ -273,14 +422,31 @@ static int wgrad_impl(const uint16_t* x, int M, int H, int W, int Cin, int x_cst
     a.nct_o = Cout / 64; a.nct_i = Cin / 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.nct_o * a.nct_i, a.nseg, groups);
-    if (ksize == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), 0, s, a);
+    const char* const pe = getenv("W2C_WGRAD_PATCH");
+    if (ksize == 3 && stride == 1 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && !(pe && atoi(pe) == 0)) {
+        constexpr int lds = 2 * (23 * 1024 + 128 * 128);
+        static unsigned long long attr_mask = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((attr_mask >> (dev & 63)) & 1ull)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_mask |= 1ull << (dev & 63);
+        }
+        hipLaunchKernelGGL(conv_wgrad_patch_kernel, grid, dim3(256), lds, s, a);
+    } else if (ksize == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, s, a);
     int rc = w2c_launch_status();
     if (rc != W2C_OK) return rc;
     const long n4 = per / 16;
-    if (oihw) hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.ws, dw, n4, a.nseg,
-                                 ksize * ksize, Cin);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.ws, dw, n4, a.nseg);
+    if (a.nseg >= 32) {                      // many segments of a small tile set: 16 threads per column
+        const dim3 rg((unsigned)((n4 + 15) / 16));
+        if (oihw) hipLaunchKernelGGL((wgrad_reduce_oihw_kernel<16>), rg, dim3(256), 0, s, a.ws, dw, n4, a.nseg, ksize * ksize, Cin);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<16>), rg, dim3(256), 0, s, a.ws, dw, n4, a.nseg);
+    } else {
+        const dim3 rg((unsigned)((n4 + 255) / 256));
+        if (oihw) hipLaunchKernelGGL((wgrad_reduce_oihw_kernel<1>), rg, dim3(256), 0, s, a.ws, dw, n4, a.nseg, ksize * ksize, Cin);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<1>), rg, dim3(256), 0, s, a.ws, dw, n4, a.nseg);
+    }
     return w2c_launch_status();
 }
 

@@ -17,6 +17,8 @@ M = 20
 for name, hw, cin, cout, ks, st in (("l1 64->64 @128", 128, 64, 64, 3, 1), ("l2.0 64->128 s2", 128, 64, 128, 3, 2), ("l2 128->128 @64", 64, 128, 128, 3, 1),
                                     ("l3.0 128->256 s2", 64, 128, 256, 3, 2), ("l3 256->256 @32", 32, 256, 256, 3, 1), ("l4.0 256->512 s2", 32, 256, 512, 3, 2),
                                     ("l4 512->512 @16", 16, 512, 512, 3, 1), ("pol2 512->256 @16", 16, 512, 256, 3, 1), ("ds 128->256 1x1 s2", 64, 128, 256, 1, 2)):
+    if os.environ.get("W2C_LAYERS") and os.environ["W2C_LAYERS"] not in name:
+        continue
     ho = (hw + 2 * (ks // 2) - ks) // st + 1
     x = torch.randn(M, hw, hw, cin, device="cuda").bfloat16()
     dy = torch.randn(M, ho, ho, cout, device="cuda").bfloat16()
