@@ -290,6 +290,17 @@ int w2c_upsample_bilinear32(const float* low, int M, int h, int w, int low_cstri
  * glow f32 NCHW [M, n_classes, h, w] = d loss / d (the low-resolution logits), same source-index rule; deterministic. */
 int w2c_upsample_bilinear32_backward(const float* gout, int M, int h, int w, int n_classes, float* glow, w2c_stream_t stream);
 
+/* ---- the 7x7 / stride-2 stem convolution (3 -> 64, backbone.py:65) in TRAINING.  The train path feeds the
+ * frames as bf16 NHWC [M, H, W, 3] (torch channels_last of [M,3,H,W]).
+ * Forward : y bf16 NHWC [M, H/2, W/2, 64] = the raw convolution (train-mode BatchNorm follows); w = the packed stem weights
+ *           [64][7][8][4] bf16 of w2c_stem_conv7x7_bn_relu.  H % 16 == 0, W % 64 == 0.
+ * Backward: the frames need no gradient; dw f32 [64][3][7][7] (the parameter's layout) from x and dy (bf16 NHWC
+ *           [M, H/2, W/2, dy_cstride >= 64]); workspace >= w2c_stem_wgrad_workspace_bytes(M, H, W); deterministic. */
+int w2c_stem_conv7x7_train_bf16(const uint16_t* x_nhwc3, int M, int H, int W, const uint16_t* w, uint16_t* y, w2c_stream_t stream);
+long long w2c_stem_wgrad_workspace_bytes(int M, int H, int W);
+int w2c_stem_wgrad_bf16(const uint16_t* x_nhwc3, int M, int H, int W, const uint16_t* dy, int dy_cstride, float* dw,
+                        void* workspace, long long workspace_bytes, w2c_stream_t stream);
+
 /* ---- cross_entropy2d (ptsemseg/loss/loss.py:5-18 = F.cross_entropy(NCHW logits -> [P, C], target,
  * weight, size_average, ignore_index)) forward and backward.
  * logits : f32 NCHW [N, C, HW]; target : int64 [N, HW]; weight : f32 [C] or NULL.

@@ -57,6 +57,9 @@ SIGNATURES = {
     "w2c_upsample_bilinear32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample32_argmax": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "w2c_upsample_bilinear32_backward": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "w2c_stem_conv7x7_train_bf16": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "w2c_stem_wgrad_workspace_bytes": [_i, _i, _i],
+    "w2c_stem_wgrad_bf16": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _ll, _vp],
     "w2c_cross_entropy2d_workspace_bytes": [_ll],
     "w2c_cross_entropy2d_forward": [_vp, _vp, _vp, _i, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp],
     "w2c_cross_entropy2d_backward": [_vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp],
@@ -95,7 +98,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = (_c.c_char_p if name in ("w2c_status_string", "w2c_last_error_string") else
                           _c.c_longlong if name in ("w2c_conv_splitk_workspace_bytes", "w2c_conv_wgrad_workspace_bytes", "w2c_bn_workspace_bytes",
-                                                     "w2c_cross_entropy2d_workspace_bytes") else _i)
+                                                     "w2c_cross_entropy2d_workspace_bytes", "w2c_stem_wgrad_workspace_bytes") else _i)
         _lib = handle
     return _lib
 

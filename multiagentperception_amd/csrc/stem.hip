@@ -26,7 +26,10 @@ constexpr int PATCH_ROWS = 21;     // 2*8 + 5 input rows for 8 output rows
 constexpr int PATCH_COLS = 72;     // 2*32 + 6 (+2 pad) input cols for 32 output cols (+ zero tap)
 constexpr int PATCH_BYTES = PATCH_ROWS * PATCH_COLS * 8;
 
-template <int COUT>
+// TRAIN = the training forward: `x` is the bf16 NHWC frame tensor the train path feeds ([M][H][W][3],
+// torch channels_last of [M,3,H,W]; B = M, N = 1) and the output is the RAW convolution (train-mode BatchNorm follows as its
+// own kernel): scale / shift are not read.
+template <int COUT, bool TRAIN = false>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, int B, int N, int H, int W,
                                                    const uint16_t* __restrict__ wpk,
                                                    const float* __restrict__ scale,
@@ -79,7 +82,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             const size_t o = ok ? (size_t)iy * W + ix : 0;              // clamp: always a valid address
             // keep the RAW loaded values: masking here would make the compiler wait for the loads right away
             // (the select cannot sink across the barriers below); the mask is applied in store_patch().
-            pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];
+            if constexpr (TRAIN) {
+                const uint16_t* x16 = reinterpret_cast<const uint16_t*>(x) + ((size_t)img * H * W + o) * 3;
+                pv[f][0] = bf16_to_f32(x16[0]); pv[f][1] = bf16_to_f32(x16[1]); pv[f][2] = bf16_to_f32(x16[2]);
+            } else {
+                pv[f][0] = xin[o]; pv[f][1] = xin[o + (size_t)H * W]; pv[f][2] = xin[o + 2 * (size_t)H * W];
+            }
             pmask = ok ? (pmask | (1u << f)) : (pmask & ~(1u << f));
         }
     };
@@ -124,14 +132,17 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ch = ct * 32 + 8 * q + 4 * lhi;
-            const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + ch);
-            const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(shift + ch);
+            f32x4_t sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!TRAIN) {
+                sc = *reinterpret_cast<const f32x4_t*>(scale + ch);
+                sh = *reinterpret_cast<const f32x4_t*>(shift + ch);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int px = (pp * MT + mt) * 32 + l31;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[mt][4 * q + r] * sc[r] + sh[r], 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = TRAIN ? acc[mt][4 * q + r] : fmaxf(acc[mt][4 * q + r] * sc[r] + sh[r], 0.f);
                 const int chunk = (ct * 4 + q) ^ (px & (CHUNKS - 1));
                 *reinterpret_cast<uint2*>(stagebuf + px * ROWBYTES + chunk * 16 + lhi * 8) =
                     make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -1100,7 +1111,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __res
     }
 }
 
-template <int COUT>
+template <int COUT, bool TRAIN = false>
 int launch_stem(const float* x, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                 const float* shift, uint16_t* y, hipStream_t s) {
     constexpr int lds = PATCH_BYTES + 256 * COUT * 2;
@@ -1108,12 +1119,12 @@ int launch_stem(const float* x, int B, int N, int H, int W, const uint16_t* w, c
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<COUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<COUT, TRAIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid((H / 2) / 8, N * B);
-    hipLaunchKernelGGL((stem_kernel<COUT>), grid, dim3(256), lds, s, x, B, N, H, W, w, scale, shift, y);
+    hipLaunchKernelGGL((stem_kernel<COUT, TRAIN>), grid, dim3(256), lds, s, x, B, N, H, W, w, scale, shift, y);
     return w2c_launch_status();
 }
 
@@ -1137,6 +1148,15 @@ extern "C" int w2c_stem_conv7x7_bn_relu(const float* x, int B, int N, int H, int
     if (Cout == 128) return launch_stem<128>(x, B, N, H, W, w, scale, shift, y, s);
     if (Cout == 64) return launch_stem<64>(x, B, N, H, W, w, scale, shift, y, s);
     return W2C_E_ARG;
+}
+
+extern "C" int w2c_stem_conv7x7_train_bf16(const uint16_t* x_nhwc3, int M, int H, int W, const uint16_t* w, uint16_t* y,
+                                           w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x_nhwc3 || !w || !y) return W2C_E_ARG;
+    if (M <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 64) != 0) return W2C_E_ARG;
+    return launch_stem<64, true>(reinterpret_cast<const float*>(x_nhwc3), M, 1, H, W, w, nullptr, nullptr, y,
+                                 reinterpret_cast<hipStream_t>(stream));
 }
 
 template <int COUT, bool U8, int BAND, int NW>

@@ -380,6 +380,43 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
 _wgrad_ws = {}
 
 
+def stem_conv7x7_train(x_nhwc3, w_packed, out=None):
+    """training forward of the 7x7/2 stem: x bf16 NHWC [M,H,W,3] -> raw conv bf16 NHWC [M,H/2,W/2,64]."""
+    dev = _need_gpu(x_nhwc3, w_packed, out)
+    M, H, W, c = x_nhwc3.shape
+    if c != 3 or x_nhwc3.dtype != BF16 or not x_nhwc3.is_contiguous() or w_packed.dtype != BF16 or w_packed.numel() != 64 * 224:
+        raise W2CError("stem_conv7x7_train: contiguous bf16 [M,H,W,3] frames and [64,224] packed weights expected")
+    if out is None:
+        out = torch.empty((M, H // 2, W // 2, 64), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_stem_conv7x7_train_bf16(_p(x_nhwc3), M, H, W, _p(w_packed), _p(out), _stream(dev)),
+              "w2c_stem_conv7x7_train_bf16")
+    return out
+
+
+def stem_wgrad(x_nhwc3, dy):
+    """dW f32 [64,3,7,7] of the stem conv from x (bf16 NHWC [M,H,W,3]) and dy (bf16 NHWC [M,H/2,W/2,>=64])."""
+    dev = _need_gpu(x_nhwc3, dy)
+    M, H, W, c = x_nhwc3.shape
+    if (c != 3 or x_nhwc3.dtype != BF16 or dy.dtype != BF16 or not x_nhwc3.is_contiguous() or not dy.is_contiguous()
+            or tuple(dy.shape[:3]) != (M, H // 2, W // 2)):
+        raise W2CError("stem_wgrad: bf16 [M,H,W,3] frames and bf16 [M,H/2,W/2,C] gradient expected")
+    lib = _native.lib()
+    need = lib.w2c_stem_wgrad_workspace_bytes(M, H, W)
+    if need < 0:
+        raise W2CError("stem_wgrad: H % 16 == 0 and W % 32 == 0 required")
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(int(need), 32 << 20), dtype=torch.uint8, device=dev)
+        _wgrad_ws[key] = ws
+    dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.w2c_stem_wgrad_bf16(_p(x_nhwc3), M, H, W, _p(dy), dy.shape[3], _p(dw), _p(ws), ws.numel(), _stream(dev)),
+              "w2c_stem_wgrad_bf16")
+    return dw
+
+
 def pack_conv_weights(weight, mode):
     """nn.Conv2d weight f32 [Cout,Cin,k,k] -> packed bf16 operand: mode 0 [1, Cout, k*k*Cin] (forward), mode 1
     [1, Cin, k*k*Cout] (flipped + transposed: the input-gradient conv).  include/w2c_hip.h w2c_pack_conv_weights_bf16."""

@@ -13,8 +13,9 @@ squeezers, policy conv1..5, the decoder's first conv: 97 % of the training FLOPs
 
 Activations travel as bf16 NHWC (torch ``channels_last``), master weights stay f32 (a mixed-precision step).  The decoder's
 256 -> 11 head runs on the same kernels with its filters zero-padded to 64 (autograd slices the gradients back).  The 7x7 stem
-(Cin = 3) is outside the kernels' shape rules and is ASSIGNED to the stock convolution -- a documented scope line, not a
-fallback: a supported conv on a GPU tensor raises if the library is missing.
+(Cin = 3; its input, the frames, needs no gradient) has its own pair: the stem kernel's training variant for the forward and
+w2c_stem_wgrad_bf16 (an im2col tile built in LDS, read back transposed) for dW.  No convolution of the path is left to
+MIOpen; a supported conv on a GPU tensor raises if the library is missing.
 ``set_train_backend("stock")`` (or W2C_TRAIN_BACKEND=stock) runs everything on stock ops, e.g. as the gradient oracle in
 tests/test_train_gpu.py.
 """
@@ -116,6 +117,34 @@ class _Conv2dHipFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _StemConvFn(torch.autograd.Function):
+    """conv1 of the ResNet trunk (3 -> 64, 7x7 / 2 / pad 3, no bias; backbone.py:65) on w2c_stem_conv7x7_train_bf16 and
+    w2c_stem_wgrad_bf16.  x: the bf16 channels_last frames [M,3,H,W]; they carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        xh = _nhwc_bf16(x)                                            # [M,H,W,3] view of the channels_last tensor
+        wp = torch.zeros((64, 7, 8, 4), dtype=BF16, device=xh.device)
+        wp[:, :, :7, :3] = weight.detach().permute(0, 2, 3, 1).to(BF16)          # [co][ky][kx (7 = 0)][ci (3 = 0)]
+        M, H, W, _ = xh.shape
+        y = torch.empty((M, 64, H // 2, W // 2), dtype=BF16, device=xh.device, memory_format=torch.channels_last)
+        ops.stem_conv7x7_train(xh, wp.reshape(64, 224), out=y.permute(0, 2, 3, 1))
+        ctx.save_for_backward(xh)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xh,) = ctx.saved_tensors
+        dw = ops.stem_wgrad(xh, _nhwc_bf16(gy)) if ctx.needs_input_grad[1] else None
+        return None, dw
+
+
+def _stem_geometry(conv, x):
+    return (conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and x.dtype == BF16 and not x.requires_grad and x.shape[2] % 16 == 0 and x.shape[3] % 64 == 0)
+
+
 def _hip_geometry(conv):
     k, s = conv.kernel_size, conv.stride
     return (k[0] == k[1] and k[0] in (1, 3) and s[0] == s[1] and s[0] in (1, 2) and conv.padding == (k[0] // 2, k[0] // 2)
@@ -138,6 +167,8 @@ class Conv2dHip(nn.Conv2d):
 
     def forward(self, x):
         if _backend == "hip" and x.is_cuda and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            if _stem_geometry(self, x):
+                return _StemConvFn.apply(x, self.weight)
             if hip_supported(self):
                 return _Conv2dHipFn.apply(x, self.weight, self.bias, self.stride[0])
             if hip_supported_padded(self):

@@ -223,8 +223,8 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
     x = torch.from_numpy(filler.synthetic_frames(b, n, s, s, 31)).to(_dev())
     labels = torch.from_numpy(filler.synthetic_labels(b * n, s, s, 31)).to(_dev())
     res = {}
-    for backend in ("stock", "stock_bf16", "hip"):
-        train_ops.set_train_backend(backend)
+    for backend in ("stock", "stock_bf16", "stock_bf16#2", "hip"):      # stock_bf16 twice: MIOpen's bf16 gradients scatter run to run
+        train_ops.set_train_backend(backend.split("#")[0])
         model.zero_grad()
         out = model(x) if arch == "Single_agent" else model(x, training=True, MO_flag=True)
         pred = out if arch == "Single_agent" else out[0]
@@ -258,8 +258,16 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
                                                     worst_gap[0], worst_gap[1]))
     # the HIP convs must cost no more accuracy than bf16 activations themselves do (stock convs on the same dtype flow):
     assert abs(res["hip"][0] - res["stock"][0]) <= max(2e-2 * abs(res["stock"][0]), 2 * abs(res["stock_bf16"][0] - res["stock"][0]))
+    # run-to-run scatter of the stock bf16 flow itself (MIOpen's bf16 weight gradients are not reproducible; behind the attention
+    # softmax two such runs agree only to cosine ~0.93 on MIMOcom, exactly 1.0 on Single_agent): the yardstick for the HIP step,
+    # which IS reproducible (every kernel on its path is deterministic)
+    _, tot_b2 = cosines("stock_bf16#2")
+    ga, gb2 = res["stock_bf16"][1], res["stock_bf16#2"][1]
+    dot = sum(float(torch.dot(ga[k].reshape(-1).double(), gb2[k].reshape(-1).double())) for k in ga)
+    scatter = 1.0 - dot / (sum(float(ga[k].double().norm() ** 2) for k in ga) ** 0.5 * sum(float(gb2[k].double().norm() ** 2) for k in ga) ** 0.5)
+    print("   stock_bf16 second run: whole-gradient cosine vs f32 %.4f; the two stock_bf16 runs differ by 1 - cos = %.4f" % (tot_b2, scatter))
     if arch != "MIMOcomWho":
-        assert tot_h >= tot_b - 0.03, (tot_h, tot_b)
+        assert tot_h >= min(tot_b, tot_b2) - max(0.03, 2.0 * scatter), (tot_h, tot_b, tot_b2, scatter)   # within twice that scatter
         assert worst_gap[0] <= (0.08 if arch == "Single_agent" else 0.2), worst_gap    # (policy path: behind the attention softmax)
     if arch != "Single_agent":
         # who2com (query: False) with the deterministic filler weights: the policy path's gradient passes a softmax over scores of
@@ -280,3 +288,34 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
             and train_ops.hip_supported(mods[k.rsplit(".", 1)[0]])]
     print("   HIP-conv weight gradients bit-identical on a repeated step: %d of %d tensors (the rest sit below a stock op whose "
           "backward is not deterministic)" % (sum(same), len(same)))
+
+
+@pytest.mark.parametrize("M,H,W", [(2, 64, 64), (3, 32, 128), (1, 128, 64)])
+def test_stem_conv_training_forward_and_weight_gradient_match_f64(M, H, W):
+    """conv1 (3 -> 64, 7x7 / 2 / pad 3) of the trunk in training: w2c_stem_conv7x7_train_bf16 for the forward,
+    w2c_stem_wgrad_bf16 (im2col tile in LDS, transposed reads, segment partials) for dW, through train_ops.Conv2dHip --
+    against f64 autograd on the same bf16-rounded operands; repeated launches are bit-identical."""
+    from multiagentperception_amd import train_ops
+    gen = torch.Generator().manual_seed(M + H + W)
+    conv = train_ops.Conv2dHip(3, 64, 7, 2, 3, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(conv.weight.shape, generator=gen) * (2.0 / 147) ** 0.5).to(BF16).float())
+    conv = conv.to(_dev())
+    x = (torch.rand(M, 3, H, W, generator=gen) - 0.45).to(BF16)
+    gy = torch.randn(M, 64, H // 2, W // 2, generator=gen).to(BF16)
+    train_ops.set_train_backend("hip")
+    outs = []
+    for _ in range(2):
+        conv.zero_grad()
+        xin = x.to(_dev()).contiguous(memory_format=torch.channels_last)
+        y = conv(xin)
+        assert y.dtype == BF16 and y.shape == (M, 64, H // 2, W // 2)
+        y.backward(gy.to(_dev()))
+        outs.append((y.detach().float().cpu(), conv.weight.grad.detach().cpu().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    w64 = conv.weight.detach().double().cpu().requires_grad_(True)
+    ref = F.conv2d(x.double(), w64, None, stride=2, padding=3)
+    ref.backward(gy.double())
+    np.testing.assert_allclose(outs[0][0].numpy(), ref.detach().float().numpy(), atol=1e-2, rtol=2 ** -7)      # bf16 output rounding
+    scale = float(w64.grad.abs().max())
+    np.testing.assert_allclose(outs[0][1].numpy(), w64.grad.float().numpy(), atol=2e-4 * scale + 1e-4, rtol=2e-4)

@@ -29,3 +29,12 @@ for k in res["stock"]:
     if "bn" in k or ".1." in k and "cbr" in k: continue
     print("%-75s %9.4f %9.4f %9.4f %9.4f %10.3e" % (k[-75:], cos(res["hip"][k], res["stock_bf16"][k]), cos(res["hip"][k], res["stock"][k]),
           cos(res["stock_bf16"][k], res["stock"][k]), cos(res["stock_bf16"][k], res["stock_bf16#2"][k]), float(res["stock"][k].norm())))
+def whole(a, b):
+    dot = na = nb = 0.0
+    for k in res["stock"]:
+        x_, y_ = res[a][k].reshape(-1).double(), res[b][k].reshape(-1).double()
+        dot += float(torch.dot(x_, y_)); na += float(x_.norm() ** 2); nb += float(y_.norm() ** 2)
+    return dot / (na ** 0.5 * nb ** 0.5)
+print("whole-gradient cosine vs f32:  hip %.4f  hip#2 %.4f  stock_bf16 %.4f  stock_bf16#2 %.4f   | hip vs hip#2 %.4f  sb16 vs sb16#2 %.4f" % (
+    whole("hip", "stock"), whole("hip#2", "stock"), whole("stock_bf16", "stock"), whole("stock_bf16#2", "stock"), whole("hip", "hip#2"),
+    whole("stock_bf16", "stock_bf16#2")))
