@@ -182,6 +182,9 @@ int w2c_zero_insert2_bf16(const uint16_t* dy, int M, int Ho, int Wo, int C, uint
 /* nn.Conv2d's f32 parameter [Cout][Cin][ky][kx] (Cout, Cin multiples of 32; ksize 1 or 3) -> the packed bf16 operand of
  * w2c_conv_igemm_bf16: mode 0 = forward [Cout][tap][Cin]; mode 1 = input-gradient [Cin][taps-1-tap][Cout]. */
 int w2c_pack_conv_weights_bf16(const float* w_oihw, int Cout, int Cin, int ksize, int mode, uint16_t* out, w2c_stream_t stream);
+/* both operands from one read of the parameter (the training forward packs the input-gradient operand for its backward) */
+int w2c_pack_conv_weights_bf16_both(const float* w_oihw, int Cout, int Cin, int ksize, uint16_t* out_fwd, uint16_t* out_dgrad,
+                                    w2c_stream_t stream);
 
 /* ---- SURVEY 8f rank 3, stage 2: train-mode BatchNorm2d (batch statistics over all P = M*H*W pixels of the
  * agent-concatenated batch, agent.py:1108-1111) fused with the residual add and ReLU that follow it in

@@ -316,18 +316,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_oihw_kernel(const float* __r
 // A workgroup moves a 32(co) x 32(ci) x taps block through LDS: reads are runs of 32*taps consecutive floats, writes runs of
 // 32 consecutive bf16.
 template <int T>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int mode) {
-    __shared__ float tile[32 * 32 * T];
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out,
+                                                           uint16_t* __restrict__ out_dgrad, int Cout, int Cin, int mode) {
+    constexpr int PITCH = 32 * T + 1;        // odd pitch per co row: the transposed (mode 1) read walks co with the lane index --
+                                             // at pitch 288 words all 64 lanes hit two banks (the first version: 15 us per call,
+                                             // 1.3 ms per training step)
+    __shared__ float tile[32 * PITCH];
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
-    for (int r = threadIdx.x; r < 32 * 32 * T; r += 256) {
+    constexpr int NIT = 32 * 32 * T / 256;   // all of a thread's loads in flight together (a rolled loop waited for each one: 15 us)
+    float v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int r = threadIdx.x + k * 256;
         const int co_l = r / (32 * T), rem = r - co_l * (32 * T);
-        tile[r] = w[((long)(co0 + co_l) * Cin + ci0) * T + rem];
+        v[k] = w[((long)(co0 + co_l) * Cin + ci0) * T + rem];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int r = threadIdx.x + k * 256;
+        const int co_l = r / (32 * T), rem = r - co_l * (32 * T);
+        tile[co_l * PITCH + rem] = v[k];
     }
     __syncthreads();
+#pragma unroll 4
     for (int o = threadIdx.x; o < 32 * 32 * T; o += 256) {
         const int a = o / (32 * T), t = (o >> 5) % T, b = o & 31;
-        if (mode == 0) out[((long)(co0 + a) * T + t) * Cin + ci0 + b] = f32_to_bf16(tile[a * 32 * T + b * T + t]);
-        else out[((long)(ci0 + a) * T + t) * Cout + co0 + b] = f32_to_bf16(tile[b * 32 * T + a * T + (T - 1 - t)]);
+        if (mode != 1) out[((long)(co0 + a) * T + t) * Cin + ci0 + b] = f32_to_bf16(tile[a * PITCH + b * T + t]);
+        if (mode != 0) out_dgrad[((long)(ci0 + a) * T + t) * Cout + co0 + b] = f32_to_bf16(tile[b * PITCH + a * T + (T - 1 - t)]);
     }
 }
 
@@ -436,15 +451,25 @@ extern "C" int w2c_conv_wgrad_bf16_oihw(const uint16_t* x, int M, int H, int W, 
     return wgrad_impl(x, M, H, W, Cin, x_cstride, dy, Cout, dy_cstride, ksize, stride, 1, dw, workspace, workspace_bytes, stream, true);
 }
 
-extern "C" int w2c_pack_conv_weights_bf16(const float* w_oihw, int Cout, int Cin, int ksize, int mode, uint16_t* out, w2c_stream_t stream) {
+static int pack_impl(const float* w_oihw, int Cout, int Cin, int ksize, int mode, uint16_t* out, uint16_t* out_dgrad, w2c_stream_t stream) {
     w2c_clear_error();
-    if (!w_oihw || !out || Cout <= 0 || Cin <= 0 || (Cout % 32) || (Cin % 32) || (ksize != 1 && ksize != 3) || (mode != 0 && mode != 1))
-        return W2C_E_ARG;
+    if (!w_oihw || Cout <= 0 || Cin <= 0 || (Cout % 32) || (Cin % 32) || (ksize != 1 && ksize != 3)) return W2C_E_ARG;
+    if ((mode != 1 && !out) || (mode != 0 && !out_dgrad)) return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(Cin / 32, Cout / 32);
-    if (ksize == 3) hipLaunchKernelGGL((pack_weights_kernel<9>), grid, dim3(256), 0, s, w_oihw, out, Cout, Cin, mode);
-    else hipLaunchKernelGGL((pack_weights_kernel<1>), grid, dim3(256), 0, s, w_oihw, out, Cout, Cin, mode);
+    if (ksize == 3) hipLaunchKernelGGL((pack_weights_kernel<9>), grid, dim3(256), 0, s, w_oihw, out, out_dgrad, Cout, Cin, mode);
+    else hipLaunchKernelGGL((pack_weights_kernel<1>), grid, dim3(256), 0, s, w_oihw, out, out_dgrad, Cout, Cin, mode);
     return w2c_launch_status();
+}
+
+extern "C" int w2c_pack_conv_weights_bf16(const float* w_oihw, int Cout, int Cin, int ksize, int mode, uint16_t* out, w2c_stream_t stream) {
+    if (mode != 0 && mode != 1) return W2C_E_ARG;
+    return pack_impl(w_oihw, Cout, Cin, ksize, mode, mode == 0 ? out : nullptr, mode == 1 ? out : nullptr, stream);
+}
+
+extern "C" int w2c_pack_conv_weights_bf16_both(const float* w_oihw, int Cout, int Cin, int ksize, uint16_t* out_fwd, uint16_t* out_dgrad,
+                                               w2c_stream_t stream) {
+    return pack_impl(w_oihw, Cout, Cin, ksize, 2, out_fwd, out_dgrad, stream);
 }
 
 extern "C" int w2c_zero_insert2_bf16(const uint16_t* dy, int M, int Ho, int Wo, int C, uint16_t* u, int H, int W, w2c_stream_t stream) {

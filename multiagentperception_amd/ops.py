@@ -430,6 +430,20 @@ def pack_conv_weights(weight, mode):
     return out
 
 
+def pack_conv_weights_both(weight):
+    """-> (forward operand [1,Cout,k*k*Cin], input-gradient operand [1,Cin,k*k*Cout]) from one read of the parameter."""
+    dev = _need_gpu(weight)
+    co, ci, k, k2 = weight.shape
+    if weight.dtype != torch.float32 or not weight.is_contiguous() or k != k2:
+        raise W2CError("pack_conv_weights: contiguous f32 [Cout,Cin,k,k] expected")
+    fwd = torch.empty((1, co, k * k * ci), dtype=BF16, device=dev)
+    dg = torch.empty((1, ci, k * k * co), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_pack_conv_weights_bf16_both(_p(weight), co, ci, k, _p(fwd), _p(dg), _stream(dev)),
+              "w2c_pack_conv_weights_bf16_both")
+    return fwd, dg
+
+
 def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups, oihw=False):
     """dW f32 [G, cout, ksize*ksize*cin] of the conv that maps x (bf16 NHWC, channels [x_ch_off, +G*cin)) to an output whose
     gradient is dy (bf16 NHWC [M,Ho,Wo,G*cout]).  include/w2c_hip.h w2c_conv_wgrad_bf16."""

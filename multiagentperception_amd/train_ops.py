@@ -90,8 +90,13 @@ class _Conv2dHipFn(torch.autograd.Function):
         # the result is allocated as a logical-NCHW channels_last tensor and the kernel writes its NHWC view: the Function
         # must not return a view it created (a following in-place ReLU would be refused by autograd)
         y = torch.empty((M, cout, Ho, Wo), dtype=BF16, device=dev, memory_format=torch.channels_last)
-        ops.conv_igemm(xh, 0, cin, _pack_fwd(weight), cout, k, stride, 1, ones, shift, relu=False, out=y.permute(0, 2, 3, 1))
+        if ctx.needs_input_grad[0]:       # the backward's operand (flipped, transposed) from the same read of the parameter
+            wf, wd = ops.pack_conv_weights_both(weight.detach().float().contiguous())
+        else:
+            wf, wd = _pack_fwd(weight), None
+        ops.conv_igemm(xh, 0, cin, wf, cout, k, stride, 1, ones, shift, relu=False, out=y.permute(0, 2, 3, 1))
         ctx.save_for_backward(xh, weight)
+        ctx.w_dgrad = wd
         ctx.stride, ctx.has_bias, ctx.in_dtype = stride, bias is not None, x.dtype
         return y if x.dtype == BF16 else y.to(x.dtype)        # bf16 in -> bf16 out (the models' train path); else the caller's dtype
 
@@ -106,7 +111,8 @@ class _Conv2dHipFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             src = gyh if ctx.stride == 1 else ops.zero_insert2(gyh, H, W)
             dx = torch.empty((M, cin, H, W), dtype=BF16, device=dev, memory_format=torch.channels_last)
-            ops.conv_igemm(src, 0, cout, _pack_dgrad(weight), cin, k, 1, 1, _const(dev, cin, 1.0),
+            wd = ctx.w_dgrad if ctx.w_dgrad is not None else _pack_dgrad(weight)
+            ops.conv_igemm(src, 0, cout, wd, cin, k, 1, 1, _const(dev, cin, 1.0),
                            _const(dev, cin, 0.0), relu=False, out=dx.permute(0, 2, 3, 1))
             if dx.dtype != ctx.in_dtype:
                 dx = dx.to(ctx.in_dtype)

@@ -61,6 +61,8 @@ def test_pack_conv_weights_equals_the_torch_permutes(cout, cin, ks):
     assert torch.equal(fwd, w.permute(0, 2, 3, 1).reshape(1, cout, -1).to(BF16))
     dg = ops.pack_conv_weights(w, 1)
     assert torch.equal(dg, w.flip(2, 3).permute(1, 2, 3, 0).reshape(1, cin, -1).to(BF16))
+    f2, d2 = ops.pack_conv_weights_both(w)
+    assert torch.equal(f2, fwd) and torch.equal(d2, dg)
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,hw,bias", [(64, 64, 3, 1, 16, False), (64, 128, 3, 2, 32, False), (128, 256, 1, 2, 16, False),
@@ -268,7 +270,8 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
     print("   stock_bf16 second run: whole-gradient cosine vs f32 %.4f; the two stock_bf16 runs differ by 1 - cos = %.4f" % (tot_b2, scatter))
     if arch != "MIMOcomWho":
         assert tot_h >= min(tot_b, tot_b2) - max(0.03, 2.0 * scatter), (tot_h, tot_b, tot_b2, scatter)   # within twice that scatter
-        assert worst_gap[0] <= (0.08 if arch == "Single_agent" else 0.2), worst_gap    # (policy path: behind the attention softmax)
+        if arch == "Single_agent":            # (multi-agent models: the policy path sits behind the attention softmax and its
+            assert worst_gap[0] <= 0.08, worst_gap   #  per-tensor cosines scatter by +-0.2 between two STOCK runs; value path below)
     if arch != "Single_agent":
         # who2com (query: False) with the deterministic filler weights: the policy path's gradient passes a softmax over scores of
         # magnitude ~30 and is chaotic -- the stock bf16 flow itself lands at cosine -0.70 or +0.85 of the f32 gradient from one
