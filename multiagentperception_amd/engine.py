@@ -540,7 +540,8 @@ class SRMSEngine:
     """LearnWhen2Com / LearnWho2Com (single requester = agent 0, five agents hard-coded: agent.py:556,766) on the same
     kernels.  'unified': one value encoder for all five agents, run side by side with the policy encoder.
     'only_normal_agents' (agent.py:823-830): the policy encoder + normal_encoder run side by side on all five frames
-    (agent 0's normal-encoder map is unused) and degarded_encoder runs alone on the requester's frames."""
+    (agent 0's normal-encoder map is unused) and degarded_encoder runs alone on the requester's frames.
+    Anything else (agent.py:832-836): five separate value encoders, one per agent, next to the policy encoder."""
 
     N = 5
     _head_plan = CommEngine._head_plan
@@ -559,8 +560,11 @@ class SRMSEngine:
             self.trunk = TrunkPlan([model.normal_encoder, pn.img_encoder])
             self.trunk0 = TrunkPlan([model.degarded_encoder])
         else:
-            raise ops.W2CError("shared_img_encoder=%r (five separate encoders, agent.py:832-836) is not on the HIP path; no "
-                               "reference config selects it" % (enc,))
+            # five separate value encoders (agent.py:832-836; no reference config selects it): the policy encoder runs alone
+            # on all five frames, encoder i on agent i's frames
+            self.trunk = TrunkPlan([pn.img_encoder])
+            self.trunk0 = None
+            self.trunks5 = [TrunkPlan([getattr(model, "encoder%d" % (i + 1))]) for i in range(self.N)]
         self.policy = [ConvPlan([c.cbr_unit[0]], [c.cbr_unit[1]], relu=True)
                        for c in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)]
         self._heads = {}
@@ -575,13 +579,17 @@ class SRMSEngine:
         """x f32 [B,15,H,W] -> pred f32 [B,n_cls,H,W], prob [B,K,1] (K = 5, or 4 for who), coef [B,K,1], action [B,1], nnz [B]."""
         B, N = x.shape[0], self.N
         sq = self.trunk.run(x, N)                                       # [5B,h,w,1024]: V | policy map
-        if self.trunk0 is not None:
+        pol_off = self.feat
+        if getattr(self, "trunks5", None) is not None:                  # sq = the policy map alone [5B,h,w,512]
+            vcs_src = torch.cat([t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1) for i, t in enumerate(self.trunks5)], 0)
+            pol_off = 0
+        elif self.trunk0 is not None:
             v = sq[..., :self.feat].contiguous()
             v[:B] = self.trunk0.run(x[:, 0:3].contiguous(), 1)
             vcs_src = v
         else:
             vcs_src = sq
-        y = self.policy[0].run(sq, x_ch_off=self.feat)
+        y = self.policy[0].run(sq, x_ch_off=pol_off)
         for c in self.policy[1:]:
             y = c.run(y)
         outs = self._head_plan(y).run(y)
