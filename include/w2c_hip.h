@@ -190,13 +190,13 @@ int w2c_pack_conv_weights_bf16_both(const float* w_oihw, int Cout, int Cin, int 
  * agent-concatenated batch, agent.py:1108-1111) fused with the residual add and ReLU that follow it in
  * conv2DBatchNormRelu (models/utils.py:118-120) and the third-party BasicBlock.  x, y, residual, dy, dx : dense bf16 NHWC
  * [P][C] (C multiple of 8, <= 2048).  Forward: mean/var over P, running stats updated in place with `momentum` (unbiased
- * var, as nn.BatchNorm2d; pass NULL to skip), y = act(gamma*(x-mean)*rstd + beta (+ residual)); saves mean, rstd [C].
+ * var, as nn.BatchNorm2d; pass NULL to skip; the int64 step counter num_batches_tracked is incremented when given), y = act(gamma*(x-mean)*rstd + beta (+ residual)); saves mean, rstd [C].
  * Backward: dyr = dy*[y>0] (y_or_null = the forward's output when relu was applied), dbeta = sum dyr, dgamma = sum dyr*xhat,
  * dx = gamma*rstd*(dyr - dbeta/P - xhat*dgamma/P), d_residual = dyr (dres_or_null).  Deterministic two-level reductions;
  * `workspace` >= w2c_bn_workspace_bytes(P, C); ab / k123: [2][C] / [3][C] f32 scratch. */
 long long w2c_bn_workspace_bytes(long long P, int C);
 int w2c_bn_train_forward(const uint16_t* x, long long P, int C, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float momentum, float eps,
+                         float* running_mean, float* running_var, long long* num_batches_tracked_or_null, float momentum, float eps,
                          const uint16_t* residual, int relu, uint16_t* y,
                          float* mean, float* rstd, float* ab, void* workspace, long long workspace_bytes, w2c_stream_t stream);
 int w2c_bn_train_backward(const uint16_t* dy, const uint16_t* y_or_null, const uint16_t* x, long long P, int C,

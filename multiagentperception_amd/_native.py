@@ -43,7 +43,7 @@ SIGNATURES = {
     "w2c_pack_conv_weights_bf16_both": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "w2c_zero_insert2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "w2c_bn_workspace_bytes": [_ll, _i],
-    "w2c_bn_train_forward": [_vp, _ll, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
+    "w2c_bn_train_forward": [_vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
     "w2c_bn_train_backward": [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
     "w2c_maxpool3x3s2_train_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "w2c_maxpool3x3s2_train_backward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],

@@ -100,8 +100,9 @@ __device__ __forceinline__ void wave_sum2(const float* __restrict__ partial, int
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partial, int nchunk, long P, int C, float eps,
                                                               float momentum, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var, float* __restrict__ mean,
-                                                              float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ b) {
+                                                              float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a,
+                                                              float* __restrict__ b) {
     // one wave per channel: lane l adds chunks l, l+64, ... in order (f64), then a fixed shuffle tree -- deterministic
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C) {
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
         const float av = gamma[c] * r;
         a[c] = av;
         b[c] = beta[c] - (float)m * av;
+        if (num_batches_tracked && c == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's step counter (one launch less per layer)
         if (running_mean) {
             const double unbiased = P > 1 ? var * (double)P / (double)(P - 1) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
@@ -219,7 +221,7 @@ extern "C" long long w2c_bn_workspace_bytes(long long P, int C) {
 }
 
 extern "C" int w2c_bn_train_forward(const uint16_t* x, long long P, int C, const float* gamma, const float* beta,
-                                    float* running_mean, float* running_var, float momentum, float eps,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
                                     const uint16_t* residual, int relu, uint16_t* y,
                                     float* mean, float* rstd, float* ab /* [2][C] scratch */, void* workspace,
                                     long long workspace_bytes, w2c_stream_t stream) {
@@ -233,7 +235,7 @@ extern "C" int w2c_bn_train_forward(const uint16_t* x, long long P, int C, const
     const size_t lds = (size_t)(256 / (C >> 3)) * 2 * C * 4;
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(n), dim3(256), lds, s, x, nullptr, nullptr, nullptr, nullptr, (long)P, C, ppc, part);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, n, (long)P, C, eps, momentum, gamma, beta,
-                       running_mean, running_var, mean, rstd, ab, ab + C);
+                       running_mean, running_var, num_batches_tracked, mean, rstd, ab, ab + C);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(P * (C >> 3))), dim3(256), 0, s, x, ab, ab + C, residual, relu, (long)P, C, y);
     return w2c_launch_status();
 }

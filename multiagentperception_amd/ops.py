@@ -504,7 +504,8 @@ def _bn_workspace(dev, P, C):
     return ws
 
 
-def bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=True, out=None):
+def bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=True, out=None,
+                     num_batches_tracked=None):
     """x dense bf16 NHWC [..., C] -> (y bf16 same shape, mean f32 [C], rstd f32 [C]); running stats updated in place
     (None to skip).  include/w2c_hip.h w2c_bn_train_forward."""
     dev = _need_gpu(x, gamma, beta, running_mean, running_var, residual)
@@ -518,8 +519,10 @@ def bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, r
     stats = torch.empty((4, C), dtype=torch.float32, device=dev)          # mean | rstd | a | b
     ws = _bn_workspace(dev, P, C)
     with torch.cuda.device(dev):
+        if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or num_batches_tracked.device != dev):
+            raise W2CError("bn: num_batches_tracked must be an int64 tensor on the activations' device")
         check(_native.lib().w2c_bn_train_forward(_p(x), P, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                                 float(momentum), float(eps), _p(residual), 1 if relu else 0, _p(y),
+                                                 _p(num_batches_tracked), float(momentum), float(eps), _p(residual), 1 if relu else 0, _p(y),
                                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), _p(ws),
                                                  ws.numel(), _stream(dev)), "w2c_bn_train_forward")
     return y, stats[0], stats[1]

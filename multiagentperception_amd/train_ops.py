@@ -215,13 +215,13 @@ class _BnActFn(torch.autograd.Function):
     threshold-backward kernels, deterministic reductions."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, nbt=None):
         xh = x.permute(0, 2, 3, 1)                                   # bf16 channels_last -> dense NHWC view
         rh = None if residual is None else _nhwc_bf16(residual)
         M, H, W, C = xh.shape
         y = torch.empty((M, C, H, W), dtype=BF16, device=x.device, memory_format=torch.channels_last)   # not a view (see _Conv2dHipFn)
         _, mean, rstd = ops.bn_train_forward(xh, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
-                                             residual=rh, relu=relu, out=y.permute(0, 2, 3, 1))
+                                             residual=rh, relu=relu, out=y.permute(0, 2, 3, 1), num_batches_tracked=nbt)
         ctx.save_for_backward(xh, y if relu else None, gamma, mean, rstd)
         ctx.has_res = residual is not None
         ctx.res_dtype = None if residual is None else residual.dtype
@@ -239,7 +239,7 @@ class _BnActFn(torch.autograd.Function):
             dro = dres.permute(0, 3, 1, 2)
             if dro.dtype != ctx.res_dtype:
                 dro = dro.to(ctx.res_dtype)
-        return dxo, dgamma, dbeta, None, None, dro, None, None, None
+        return dxo, dgamma, dbeta, None, None, dro, None, None, None, None
 
 
 def bn_act(bn, x, relu, residual=None):
@@ -249,9 +249,9 @@ def bn_act(bn, x, relu, residual=None):
     if (_backend == "hip" and bn.training and x.is_cuda and x.dtype == BF16 and x.dim() == 4 and x.shape[1] % 8 == 0
             and x.is_contiguous(memory_format=torch.channels_last) and bn.affine and bn.track_running_stats
             and bn.momentum is not None):
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
-        return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu, bn.momentum, bn.eps)
+        # (num_batches_tracked is incremented by the finalize kernel of the forward: 47 one-element launches per step otherwise)
+        return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu, bn.momentum, bn.eps,
+                              bn.num_batches_tracked)
     y = bn(x)
     if residual is not None:
         y = y + residual
