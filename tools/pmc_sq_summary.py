@@ -8,8 +8,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_kernel<[^>]*>|conv3x3_patch_kernel<[^>]*>|conv3x3_c\d+_regw_kernel<[^>]*>|stem_pool2?_kernel<[^>]*>|"
-                  r"[A-Za-z0-9_]+_kernel\b)", name)
+    m = re.search(r"([A-Za-z0-9_]+_kernel(?:<[^>]*>)?)", name)
     return m.group(1) if m else None
 
 
