@@ -162,6 +162,21 @@ int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int W, int Cin,
                       uint16_t* idt_bf16, int idt_cstride,
                       const void* zero_page, int variant, w2c_stream_t stream);
 
+/* ---- a whole stride-1 BasicBlock with Cin = Cout = 64 (layer1 of the third-party resnet18, backbone.py:63-69) in ONE launch:
+ *   y = relu(bn2(conv2 3x3 (relu(bn1(conv1 3x3 (x))))) + x)
+ * The intermediate map never leaves the CU (csrc/conv_block.hip: flattened row strips, x and t in LDS rings, conv1 and conv2 on
+ * different waves with their weights in registers).  Bit-identical to the two w2c_conv_igemm_bf16 launches it replaces.
+ * x, y : bf16 NHWC [M][H][W][x_cstride | y_cstride], group g in channels [64 g, 64 g + 64); x != y (halo rows are re-read).
+ * w1, w2 : [groups][64][9][64] bf16 packed like every conv here; scale / shift : folded eval BatchNorm, [groups*64] f32.
+ * W % 8 == 0 and (W <= 128 or W % 128 == 0); tensors < 2 GiB.  max_workgroups <= 0: one workgroup per CU (tests pass small
+ * values to exercise multi-strip workgroups). */
+/* debug: the next w2c_conv_block_c64 call of this thread writes per-wave phase cycle sums to buf (tools/block_phases.py) */
+int w2c_debug_block_phases(void* buf);
+int w2c_conv_block_c64(const uint16_t* x, int M, int H, int W, int x_cstride,
+                       const uint16_t* w1, const float* scale1, const float* shift1,
+                       const uint16_t* w2, const float* scale2, const float* shift2,
+                       int groups, uint16_t* y, int y_cstride, int max_workgroups, w2c_stream_t stream);
+
 /* ---- SURVEY 8f rank 3 (training backward, first stage): gradients of the path's 3x3 / 1x1 convolutions
  * (nn.Conv2d under loss.backward(), trainer.py:669-673).
  * Weight gradient: dw[g][co][tap][ci] = sum_p dy[p][g*Cout+co] * x[p @ tap][g*Cin+ci], f32, the layout of the packed

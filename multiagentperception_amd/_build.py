@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libw2c_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "bn_train.hip", "stem.hip", "stem_train.hip", "comm_attn.hip", "upsample.hip", "loss.hip"]
+SOURCES = ["conv_igemm.hip", "conv_block.hip", "conv_wgrad.hip", "bn_train.hip", "stem.hip", "stem_train.hip", "comm_attn.hip", "upsample.hip", "loss.hip"]
 
 
 def _hipcc():
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+           "-Wno-unused-value"] + os.environ.get("W2C_EXTRA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -36,6 +36,8 @@ SIGNATURES = {
                            _vp, _i, _vp],
     "w2c_conv_s2_block": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i,
                           _vp, _i, _vp],
+    "w2c_debug_block_phases": [_vp],
+    "w2c_conv_block_c64": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "w2c_conv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_conv_wgrad_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _ll, _vp],
     "w2c_conv_wgrad_bf16_oihw": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _ll, _vp],

@@ -377,6 +377,37 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
     return t16, t8, idt
 
 
+def conv_block_c64(x, w1, scale1, shift1, w2, scale2, shift2, groups, out=None, max_workgroups=0):
+    """A whole 64-channel stride-1 BasicBlock in one launch (include/w2c_hip.h w2c_conv_block_c64):
+    y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).  x bf16 NHWC [M,H,W,cs], group g in channels [64g, 64g+64);
+    w1 / w2 [G,64,576] bf16 packed."""
+    dev = _need_gpu(x, w1, scale1, shift1, w2, scale2, shift2, out)
+    M, H, W, xcs = x.shape
+    if x.dtype != BF16 or w1.dtype != BF16 or w2.dtype != BF16 or w1.shape != (groups, 64, 576) or w2.shape != (groups, 64, 576):
+        raise W2CError("conv_block_c64: bf16 x and [G,64,576] bf16 packed weights expected")
+    if xcs < groups * 64:
+        raise W2CError("conv_block_c64: channels outside the tensor")
+    if out is None:
+        out = torch.empty((M, H, W, groups * 64), dtype=BF16, device=dev)
+    if out.dtype != BF16 or out.shape[:3] != x.shape[:3] or out.shape[3] < groups * 64 or out.data_ptr() == x.data_ptr():
+        raise W2CError("conv_block_c64: out must be a different bf16 NHWC tensor of the same spatial shape")
+    timer = getattr(_tls, "conv_timer", None)
+    if timer is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_block_c64(_p(x), M, H, W, xcs, _p(w1), _p(scale1), _p(shift1), _p(w2), _p(scale2), _p(shift2),
+                                               groups, _p(out), out.shape[3], int(max_workgroups), _stream(dev)),
+              "w2c_conv_block_c64")
+    if timer is not None:
+        ev1.record(torch.cuda.current_stream(dev))
+        flops = 2.0 * 2.0 * M * H * W * 64 * 576 * groups
+        nbytes = 2 * M * H * W * 64 * groups * 2 + 2 * groups * 64 * 576 * 2
+        timer.records.append((ev0, ev1, flops, (M * H * W, 64, 64, "3,3 block", 1, groups), nbytes))
+    return out
+
+
 _wgrad_ws = {}
 
 
