@@ -298,6 +298,16 @@ int w2c_comm_graph_projected(const float* query, const float* tproj, int B, int 
 int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* coef, int B, int N, int q_lo, int q_n,
                     int hw, int C, int append_own, uint16_t* out, int out_cstride, w2c_stream_t stream);
 
+/* K6 + K7 in ONE launch (w2c_comm_graph_projected followed by w2c_fuse_values, same arithmetic and outputs): every workgroup
+ * of a sample recomputes that sample's graph in LDS and fuses its share of the pixels; one workgroup per sample writes
+ * prob / coef / action / nnz_offdiag.  Arguments as in the two calls it replaces. */
+int w2c_comm_graph_fuse(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
+                        float thres, float tie_bias, int q_lo, int q_n,
+                        float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                        const uint16_t* v, int v_cstride, int hw, int C, int append_own,
+                        uint16_t* out, int out_cstride, w2c_stream_t stream);
+
+
 /* ---- K9: bilinear x32 upsample, align_corners=False (backbone.py:160).
  * low : f32 NHWC [M, h, w, low_cstride] (first n_classes channels used)
  * out : f32 NCHW [M, n_classes, 32h, 32w] */

@@ -262,6 +262,48 @@ __device__ __forceinline__ void wave_argmax(float& best, int& bidx) {
     }
 }
 
+// One query column of the graph for sample b (lanes = keys): -> this lane's prob_action entry `pr`, fusion coefficient `cf`,
+// the column's action, and whether the entry counts towards num_connect.  Shared by comm_graph_kernel and graph_fuse_kernel so
+// the two produce the same bits.
+__device__ __forceinline__ bool graph_column(const float* __restrict__ query, const float* __restrict__ T, int B, int N, int Dq,
+                                             int who, int mode, float thres, float tie_bias, int b, int q, int ql, int lane,
+                                             float& pr, float& cf, int& act) {
+    const int k = lane;
+    float s = -INFINITY;
+    if (k < N) {
+        const float* trow = T + (size_t)(k * B + b) * (Dq + 1);
+        float d = trow[Dq];
+        if (query) {
+            const float* qrow = query + (size_t)(ql * B + b) * Dq;   // rows of the produced query agents only
+            for (int j = 0; j < Dq; ++j) d = fmaf(trow[j], qrow[j], d);
+        } else {
+            for (int j = 0; j < Dq; ++j) d += trow[j];                 // all-ones query (agent.py:1143,1370)
+        }
+        s = (who && k == q) ? -INFINITY : d;                           // who: diagonal stripped (agent.py:310-318)
+    }
+    const float mx = wave_max(s);
+    const float e = (k < N && s > -INFINITY) ? expf(s - mx) : 0.f;
+    const float den = wave_sum(e);
+    const float p0 = e / den;                                           // softmax over keys (agent.py:274)
+    pr = (k < N && !who && k == q) ? p0 + tie_bias : p0;                // prob_action (agent.py:1164-1167)
+    float best = (k < N) ? pr : -INFINITY;
+    int bidx = (k < N) ? k : 0x7fffffff;
+    wave_argmax(best, bidx);
+    if (mode == 0) cf = p0;                                             // softmax / training (agent.py:1155-1161)
+    else if (mode == 1) cf = (k == bidx) ? 1.f : 0.f;                   // argmax_select (agent.py:1040-1041)
+    else cf = (pr > thres) ? pr : 0.f;                                  // activated_select (agent.py:1062)
+    act = bidx;
+    if (mode != 0 && !who) {
+        // MIMOcom returns argmax over keys of the connect matrix (agent.py:1189,1200);
+        // MIMOcomWho always argmax(prob_action) (agent.py:1389,1408,1419)
+        float cb = (k < N) ? cf : -INFINITY;
+        int ci = (k < N) ? k : 0x7fffffff;
+        wave_argmax(cb, ci);
+        act = ci;
+    }
+    return k < N && k != q && cf != 0.f;
+}
+
 __global__ __launch_bounds__(256) void comm_graph_kernel(const float* __restrict__ query, const float* __restrict__ T,
                                                          int B, int N, int Dq, int who, int mode, float thres,
                                                          float tie_bias, int q_lo, int q_n,
@@ -274,46 +316,13 @@ __global__ __launch_bounds__(256) void comm_graph_kernel(const float* __restrict
     __syncthreads();
     int local_nnz = 0;
     for (int ql = wave; ql < q_n; ql += 4) {               // one wave per query column
-        const int q = q_lo + ql;
-        const int k = lane;
-        float s = -INFINITY;
-        if (k < N) {
-            const float* trow = T + (size_t)(k * B + b) * (Dq + 1);
-            float d = trow[Dq];
-            if (query) {
-                const float* qrow = query + (size_t)(ql * B + b) * Dq;   // rows of the produced query agents only
-                for (int j = 0; j < Dq; ++j) d = fmaf(trow[j], qrow[j], d);
-            } else {
-                for (int j = 0; j < Dq; ++j) d += trow[j];                 // all-ones query (agent.py:1143,1370)
-            }
-            s = (who && k == q) ? -INFINITY : d;                           // who: diagonal stripped (agent.py:310-318)
-        }
-        const float mx = wave_max(s);
-        const float e = (k < N && s > -INFINITY) ? expf(s - mx) : 0.f;
-        const float den = wave_sum(e);
-        const float p0 = e / den;                                           // softmax over keys (agent.py:274)
-        const float pr = (k < N && !who && k == q) ? p0 + tie_bias : p0;    // prob_action (agent.py:1164-1167)
-        float best = (k < N) ? pr : -INFINITY;
-        int bidx = (k < N) ? k : 0x7fffffff;
-        wave_argmax(best, bidx);
-        float cf;                                                           // coefficient fusing the RETURNED prediction
-        if (mode == 0) cf = p0;                                             // softmax / training (agent.py:1155-1161)
-        else if (mode == 1) cf = (k == bidx) ? 1.f : 0.f;                   // argmax_select (agent.py:1040-1041)
-        else cf = (pr > thres) ? pr : 0.f;                                  // activated_select (agent.py:1062)
-        int act = bidx;
-        if (mode != 0 && !who) {
-            // MIMOcom returns argmax over keys of the connect matrix (agent.py:1189,1200);
-            // MIMOcomWho always argmax(prob_action) (agent.py:1389,1408,1419)
-            float cb = (k < N) ? cf : -INFINITY;
-            int ci = (k < N) ? k : 0x7fffffff;
-            wave_argmax(cb, ci);
-            act = ci;
-        }
-        if (k < N) {
-            const size_t o = ((size_t)b * N + k) * q_n + ql;
+        float pr, cf;
+        int act;
+        if (graph_column(query, T, B, N, Dq, who, mode, thres, tie_bias, b, q_lo + ql, ql, lane, pr, cf, act)) ++local_nnz;
+        if (lane < N) {
+            const size_t o = ((size_t)b * N + lane) * q_n + ql;
             prob[o] = pr;
             coef[o] = cf;
-            if (k != q && cf != 0.f) ++local_nnz;
         }
         if (lane == 0) action[(size_t)b * q_n + ql] = act;
     }
@@ -334,6 +343,76 @@ __global__ __launch_bounds__(256) void fuse_kernel(const uint16_t* __restrict__ 
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < N * q_n; i += 256) cs[i] = coef[(size_t)b * N * q_n + i];
     __syncthreads();
+    const int CG = C >> 3;
+    const int total = hw * CG;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int px = id / CG, cg = id - px * CG;
+        for (int ql = 0; ql < q_n; ++ql) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int k = 0; k < N; ++k) {
+                const float c = cs[k * q_n + ql];
+                if (c == 0.f) continue;
+                const uint4 u = *reinterpret_cast<const uint4*>(v + ((size_t)(k * B + b) * hw + px) * vcs + cg * 8);
+                const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] = fmaf(c, bf16_to_f32((uint16_t)(wv[e] & 0xFFFFu)), acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(c, bf16_to_f32((uint16_t)(wv[e] >> 16)), acc[2 * e + 1]);
+                }
+            }
+            uint4 o;
+            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+            uint16_t* orow = out + ((size_t)(ql * B + b) * hw + px) * ocs;
+            *reinterpret_cast<uint4*>(orow + cg * 8) = o;
+            if (append_own) {
+                const uint4 own = *reinterpret_cast<const uint4*>(v + ((size_t)((q_lo + ql) * B + b) * hw + px) * vcs + cg * 8);
+                *reinterpret_cast<uint4*>(orow + C + cg * 8) = own;
+            }
+        }
+    }
+}
+
+// K6 + K7 in one launch: every workgroup of sample b recomputes b's graph (N x q_n dot products of Dq+1 values: ~2 us of
+// latency, far less than a kernel boundary plus a 4-workgroup launch of its own) into LDS and fuses its share of the pixels with
+// it; workgroup x = 0 of each sample also writes prob / coef / action / nnz.  Same arithmetic as the two separate kernels.
+__global__ __launch_bounds__(256) void graph_fuse_kernel(const float* __restrict__ query, const float* __restrict__ T,
+                                                         int B, int N, int Dq, int who, int mode, float thres, float tie_bias,
+                                                         int q_lo, int q_n, float* __restrict__ prob, float* __restrict__ coef,
+                                                         int64_t* __restrict__ action, int32_t* __restrict__ nnz,
+                                                         const uint16_t* __restrict__ v, int vcs, int hw, int C, int append_own,
+                                                         uint16_t* __restrict__ out, int ocs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cs = reinterpret_cast<float*>(smem);          // [N][q_n] for this b, then one int
+    int* cnt = reinterpret_cast<int*>(cs + N * q_n);
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool writer = blockIdx.x == 0;
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    int local_nnz = 0;
+    for (int ql = wave; ql < q_n; ql += 4) {
+        float pr, cf;
+        int act;
+        if (graph_column(query, T, B, N, Dq, who, mode, thres, tie_bias, b, q_lo + ql, ql, lane, pr, cf, act)) ++local_nnz;
+        if (lane < N) {
+            cs[lane * q_n + ql] = cf;
+            if (writer) {
+                const size_t o = ((size_t)b * N + lane) * q_n + ql;
+                prob[o] = pr;
+                coef[o] = cf;
+            }
+        }
+        if (writer && lane == 0) action[(size_t)b * q_n + ql] = act;
+    }
+    if (writer) {
+        local_nnz = (int)wave_sum((float)local_nnz);
+        if (lane == 0 && local_nnz) atomicAdd(cnt, local_nnz);
+    }
+    __syncthreads();
+    if (writer && tid == 0) nnz[b] = *cnt;
     const int CG = C >> 3;
     const int total = hw * CG;
     for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
@@ -458,5 +537,26 @@ extern "C" int w2c_fuse_values(const uint16_t* v, int v_cstride, const float* co
     const size_t lds = (size_t)N * q_n * 4;
     hipLaunchKernelGGL(fuse_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        v, v_cstride, coef, B, N, q_lo, q_n, hw, C, append_own, out, out_cstride);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_comm_graph_fuse(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
+                                   float thres, float tie_bias, int q_lo, int q_n,
+                                   float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                                   const uint16_t* v, int v_cstride, int hw, int C, int append_own,
+                                   uint16_t* out, int out_cstride, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!tproj || !prob || !coef || !action || !nnz_offdiag || !v || !out) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
+    if (q_lo < 0 || q_n <= 0 || q_lo + q_n > N) return W2C_E_ARG;
+    if (hw <= 0 || C <= 0 || (C % 8) != 0 || (v_cstride % 8) != 0 || (out_cstride % 8) != 0) return W2C_E_ARG;
+    if (v_cstride < C || out_cstride < (append_own ? 2 * C : C)) return W2C_E_ARG;
+    const int total = hw * (C / 8);
+    int bx = (total + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const size_t lds = (size_t)N * q_n * 4 + 16;
+    hipLaunchKernelGGL(graph_fuse_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), query, tproj, B, N, Dq,
+                       who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag, v, v_cstride, hw, C, append_own,
+                       out, out_cstride);
     return w2c_launch_status();
 }

@@ -460,9 +460,16 @@ class CommEngine:
     def graph_and_low(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
         """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decoder convs
         (everything up to the low-resolution logits)."""
-        prob, coef, action, nnz = ops.comm_graph_projected(querys_local, keys_all, B, N, self.who, mode,
-                                                           q_lo=q_lo, q_n=q_n)
-        fused = ops.fuse_values(sq_all, self.feat, coef, B, N, q_lo, q_n, append_own=self.who)
+        if os.environ.get("W2C_NO_GRAPH_FUSE"):            # A/B: the two launches this replaces (same bits)
+            pack, prob, action, nnz = ops.graph_outputs(sq_all.device, B, N, q_n)
+            p2, coef, a2, n2 = ops.comm_graph_projected(querys_local, keys_all, B, N, self.who, mode, q_lo=q_lo, q_n=q_n)
+            prob.copy_(p2); action.copy_(a2); nnz.copy_(n2)
+            fused = ops.fuse_values(sq_all, self.feat, coef, B, N, q_lo, q_n, append_own=self.who)
+            self._last_pack = pack
+            return self.decoder.low_logits(fused), prob, action, nnz
+        fused, prob, _, action, nnz, pack = ops.comm_graph_fuse(querys_local, keys_all, sq_all, self.feat, B, N, self.who, mode,
+                                                                q_lo=q_lo, q_n=q_n, append_own=self.who)
+        self._last_pack = pack             # prob / action / nnz are views of this one buffer (ops.graph_outputs)
         return self.decoder.low_logits(fused), prob, action, nnz
 
     def graph_and_decode(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
@@ -492,11 +499,12 @@ class CommEngine:
         if entry is None:
             entry = self._capture(x, B, N, mode)
             self._graphs[key] = entry
-        s0, graph, low, prob, action, nnz = entry
+        s0, graph, low, pack = entry
         self.trunk.stem(x, N, out=s0)                       # eager: reads the caller's tensor
-        graph.replay()                                      # maxpool ... decoder convs (45 launches)
+        graph.replay()                                      # layer1 ... decoder convs
         pred = finish(low)                                   # eager: writes the caller-owned output
-        return pred, prob.clone(), action.clone(), nnz.clone()
+        prob, action, nnz = ops.carve_graph_outputs(pack.clone(), B, N, N)     # caller-owned copies: ONE copy of the packed trio
+        return pred, prob, action, nnz
 
     def _capture(self, x, B, N, mode):
         """Capture everything between the stem and the final upsample into one HIP graph.  The stem
@@ -519,7 +527,8 @@ class CommEngine:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             low, prob, action, nnz = middle(s0)
-        return s0, graph, low, prob, action, nnz
+            pack = self._last_pack
+        return s0, graph, low, pack
 
 
 class SingleEngine:

@@ -25,22 +25,43 @@ _INFERENCE_MODES = ("softmax", "argmax_test", "activated")
 
 class _EngineCacheMixin:
     """Packed-weight cache keyed by device, dropped whenever the parameters may have changed
-    (train(), load_state_dict, .to()/.cuda()).  A dict so DataParallel replicas (shallow
-    __dict__ copies, one thread per device) share it safely: one entry per device."""
+    (train(), load_state_dict, .to()/.cuda()) and REBUILT when they did change while the module stayed in eval(): every
+    entry remembers the sum of the autograd version counters of all parameters and buffers it was packed from, and
+    _engine_for compares it on every forward (~30 us of host time for the 551 tensors) -- an optimizer.step() / EMA swap /
+    p.copy_() / pruning pass under eval() bumps a counter and the next forward repacks instead of silently running stale
+    weights and stale captured graphs.  Not seen by the counters: writes through ``p.data`` (its own version counter) and a
+    Parameter OBJECT replaced by assignment -- call invalidate_engines() after those.
+    A dict so DataParallel replicas (shallow __dict__ copies, one thread per device) share it safely: one entry per device."""
 
     def _init_engine_cache(self):
         self._engines = {}
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._engines.clear())
+        self._sig_tensors = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: (module.invalidate_engines(), None)[1])
+
+    def invalidate_engines(self):
+        """drop the packed weights / captured HIP graphs of every device (they are rebuilt by the next eval forward)"""
+        self._engines.clear()
+        self._sig_tensors = None
+        return self
+
+    def _weights_signature(self):
+        ts = self._sig_tensors
+        if ts is None:
+            ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
+        v = len(ts)
+        for t in ts:
+            v += t._version
+        return v
 
     def train(self, mode=True):
         # parameters can only change under train(): eval() -> eval() (e.g. the evaluator's model.eval() at the top of
         # every validation pass) keeps the packed weights and the captured HIP graphs
         if mode:
-            self._engines.clear()
+            self.invalidate_engines()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
-        self._engines.clear()
+        self.invalidate_engines()
         return super()._apply(fn, *a, **k)
 
     trunk_precision = "bf16"
@@ -52,7 +73,7 @@ class _EngineCacheMixin:
         if precision not in ("bf16", "fp8", "fp8-all"):
             raise ValueError("trunk precision must be 'bf16', 'fp8' or 'fp8-all'")
         self.trunk_precision = precision
-        self._engines.clear()
+        self.invalidate_engines()
         return self
 
     def _engine_for(self, x, factory):
@@ -65,12 +86,13 @@ class _EngineCacheMixin:
         if p.device != x.device:
             raise W2CError("input on %s but parameters on %s" % (x.device, p.device))
         key = (x.device.index if x.device.index is not None else torch.cuda.current_device())
-        eng = self._engines.get(key)
-        if eng is None:
+        sig = self._weights_signature()
+        entry = self._engines.get(key)
+        if entry is None or entry[1] != sig:
             with torch.no_grad():
-                eng = factory(self)
-            self._engines[key] = eng
-        return eng
+                entry = (factory(self), sig)
+            self._engines[key] = entry
+        return entry[0]
 
 
 class Single_agent(_EngineCacheMixin, nn.Module):

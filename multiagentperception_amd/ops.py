@@ -672,6 +672,46 @@ def comm_graph_projected(query, tproj, B, N, who, mode, thres=0.2, tie_bias=0.00
     return prob, coef, action, nnz
 
 
+def graph_outputs(dev, B, N, q_n):
+    """prob f32 [B,N,q_n] | action i64 [B,q_n] | nnz i32 [B] carved out of ONE buffer, so a caller that must hand out fresh
+    copies (the HIP-graph path: its outputs are static buffers) copies once instead of three times.  -> (pack, prob, action, nnz)"""
+    n_prob, n_act = B * N * q_n * 4, B * q_n * 8
+    off_act = (n_prob + 7) // 8 * 8
+    off_nnz = off_act + n_act
+    pack = torch.empty(off_nnz + B * 4, dtype=torch.uint8, device=dev)
+    return (pack,) + carve_graph_outputs(pack, B, N, q_n)
+
+
+def carve_graph_outputs(pack, B, N, q_n):
+    n_prob, n_act = B * N * q_n * 4, B * q_n * 8
+    off_act = (n_prob + 7) // 8 * 8
+    off_nnz = off_act + n_act
+    prob = pack[:n_prob].view(torch.float32).view(B, N, q_n)
+    action = pack[off_act:off_act + n_act].view(torch.int64).view(B, q_n)
+    nnz = pack[off_nnz:off_nnz + B * 4].view(torch.int32)
+    return prob, action, nnz
+
+
+def comm_graph_fuse(query, tproj, v, v_ch, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None, append_own=False):
+    """comm_graph_projected + fuse_values in one launch (w2c_comm_graph_fuse).  -> fused bf16 [q_n*B,h,w,C|2C], prob, coef,
+    action, nnz, pack (prob / action / nnz are views of `pack`, see graph_outputs)."""
+    dev = _need_gpu(query, tproj, v)
+    Dq = tproj.shape[1] - 1
+    if q_n is None:
+        q_n = N - q_lo
+    pack, prob, action, nnz = graph_outputs(dev, B, N, q_n)
+    coef = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
+    _, h, w, vcs = v.shape
+    ocs = 2 * v_ch if append_own else v_ch
+    out = torch.empty((q_n * B, h, w, ocs), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_comm_graph_fuse(_p(query), _p(tproj), B, N, Dq, 1 if who else 0, MODE_IDS[mode], float(thres),
+                                                float(tie_bias), q_lo, q_n, _p(prob), _p(coef), _p(action), _p(nnz), _p(v), vcs,
+                                                h * w, v_ch, 1 if append_own else 0, _p(out), ocs, _stream(dev)),
+              "w2c_comm_graph_fuse")
+    return out, prob, coef, action, nnz, pack
+
+
 def fuse_values(v, v_ch, coef, B, N, q_lo, q_n, append_own=False, out=None):
     """v: bf16 NHWC [N*B,h,w,vcs] (first v_ch channels are the value map) -> [q_n*B,h,w,C or 2C]."""
     dev = _need_gpu(v, coef, out)

@@ -173,3 +173,43 @@ def synthetic_labels(rows, height, width, seed, n_classes=11):
     u = uniform_pm1("labels", rows * height * width, salt=seed)
     lab = np.floor((u + 1.0) * 0.5 * n_classes).astype(np.int64)
     return np.clip(lab, 0, n_classes - 1).reshape(rows, height, width)
+
+
+# ---- structured scenes (accuracy fixtures) ---------------------------------------------------------------------------------------
+# The hashed frames above drive the decoder with spatially white features: every low-resolution cell is a class boundary and ~0.2 %
+# of the pixels sit within rounding distance of one, so a label-map comparison measures boundary density, not the kernels.  A scene
+# is what a trained model sees: a few compact regions per frame, one class each.  Integer / IEEE add-mul arithmetic only (bit-
+# identical on every host).
+_SCENE_COLORS_BGR = np.array([[40, 40, 40], [200, 60, 60], [60, 200, 60], [60, 60, 200], [200, 200, 60], [200, 60, 200],
+                              [60, 200, 200], [230, 230, 230], [120, 80, 40], [40, 120, 200], [160, 40, 120]], dtype=np.float64)
+
+
+def synthetic_scene(batch, agents, height, width, seed, n_classes=11, cell=32, sites=7):
+    """-> (frames f32 [B, 3N, H, W] like synthetic_frames, labels int64 [N*B, H, W] agent-major like the evaluator's
+    cat(labels_list, 0)).  Per SAMPLE: `sites` hashed Voronoi sites on the (H/cell x W/cell) grid, one class each (L1 distance,
+    ties to the lower site index) -- the agents of a sample look at the same scene, as the drones of AirSim-MAP do, each with its
+    own exposure (+-20 grey levels), shading direction and pixel noise (+-10), so whichever value maps the communication graph
+    mixes, the fused map still describes the labelled scene.  Every cell x cell block of a frame carries its cell's class colour."""
+    gh, gw = height // cell, width // cell
+    u = uniform_pm1("scene-sites", batch * sites * 3, salt=seed).reshape(batch, sites, 3)
+    sy = np.floor((u[..., 0] + 1.0) * 0.5 * gh).clip(0, gh - 1).astype(np.int64)
+    sx = np.floor((u[..., 1] + 1.0) * 0.5 * gw).clip(0, gw - 1).astype(np.int64)
+    sc = np.floor((u[..., 2] + 1.0) * 0.5 * n_classes).clip(0, n_classes - 1).astype(np.int64)
+    yy = np.arange(gh, dtype=np.int64)[None, None, :, None]
+    xx = np.arange(gw, dtype=np.int64)[None, None, None, :]
+    d = np.abs(yy - sy[..., None, None]) + np.abs(xx - sx[..., None, None])          # [B, sites, gh, gw]
+    near = np.argmin(d, axis=1)                                                       # first minimum: lower site index wins
+    cls = np.take_along_axis(sc[..., None, None] + 0 * d, near[:, None], axis=1)[:, 0]            # [B, gh, gw]
+    lab = np.repeat(np.repeat(cls, cell, axis=1), cell, axis=2)                       # [B, H, W]
+    col = _SCENE_COLORS_BGR[lab][:, None]                                             # [B, 1, H, W, 3]
+    noise = uniform_pm1("scene-noise", batch * agents * 3 * height * width, salt=seed).reshape(batch, agents, height, width, 3)
+    st = uniform_pm1("scene-style", batch * agents * 3, salt=seed).reshape(batch, agents, 3)
+    ys = np.arange(height, dtype=np.float64)[:, None] / height - 0.5
+    xs = np.arange(width, dtype=np.float64)[None, :] / width - 0.5
+    shade = st[..., 1, None, None] * ys[None, None] + st[..., 2, None, None] * xs[None, None]     # [B, N, H, W]
+    u8 = np.clip(np.floor(col + 20.0 * st[..., 0, None, None, None] + 24.0 * shade[..., None] + 10.0 * noise), 0, 255)
+    mean = np.array([103.939, 116.779, 123.68], dtype=np.float64)
+    img = ((u8 - mean) / 255.0).astype(np.float32)                                    # [B, N, H, W, 3 (BGR)]
+    frames = np.ascontiguousarray(img.transpose(0, 1, 4, 2, 3)).reshape(batch, agents * 3, height, width)
+    labels = np.ascontiguousarray(np.broadcast_to(lab[None], (agents,) + lab.shape)).reshape(agents * batch, height, width)
+    return frames, labels

@@ -231,9 +231,17 @@ def run_case(ref_models, ref_metrics, name, arch, yml, agent_num, batch, size, m
         t2 = np.sort(p, axis=1)[:, -2:, :]
         meta["min_top2_gap"] = float((t2[:, 1] - t2[:, 0]).min())
         meta["prob_max_mean"] = float(p.max(axis=1).mean())
+        meta["seed_policy"] = SEARCHED
+    if arch == "Single_agent":
+        meta["seed_policy"] = "nominal"
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     return meta, spec
 
+
+# what "seed" means in cases.json: the multi-agent fixtures are CONDITIONED -- easy inputs by construction.
+# tests/golden/plain_seed_cases.json lists the unconditioned seeds the GPU tests run next to them (against the oracle).
+SEARCHED = ("searched: first seed >= the nominal one whose reference P stays >= 0.04 from the 0.2 activation threshold, whose per-query "
+            "top-2 gap is >= 0.04 and whose CPU bf16-storage emulation loses <= 8e-3 of P and <= 6.5e-3 of the logits")
 
 CASES = [
     # name, arch, yml, N, B, size, modes, seed, overrides

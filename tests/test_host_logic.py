@@ -144,6 +144,33 @@ def test_engine_cache_invalidation_rules():
     assert not m._engines
 
 
+def test_engine_cache_sees_in_place_weight_changes_under_eval():
+    """optimizer.step() / EMA swaps / p.copy_() while the module stays in eval() must not leave stale packed
+    weights or captured graphs behind: the cache entry carries the sum of the tensors' version counters."""
+    from ptsemseg.models import get_model
+    m = get_model(_cfg("MIMOcom", n=2, size=128), 11).eval()
+    s0 = m._weights_signature()
+    assert m._weights_signature() == s0                      # stable
+    m.eval()
+    assert m._weights_signature() == s0                      # eval() -> eval(): nothing changed
+    w = m.decoder.output_decoder.pred[2].weight
+    with torch.no_grad():
+        w.mul_(1.0)                                          # any in-place write (what an optimizer step does)
+    s1 = m._weights_signature()
+    assert s1 != s0
+    bn = m.u_encoder.feature_backbone.feature_backbone.bn1
+    bn.running_mean.add_(0.0)                                # buffers count too (folded into the conv epilogue)
+    assert m._weights_signature() != s1
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    for p_ in m.parameters():
+        p_.grad = torch.zeros_like(p_)
+    s2 = m._weights_signature()
+    opt.step()
+    assert m._weights_signature() != s2
+    m.invalidate_engines()
+    assert m._sig_tensors is None and not m._engines
+
+
 def _replicate_like_data_parallel(module):
     """What torch.nn.parallel.replicate() leaves on a replica (torch/nn/parallel/replicate.py), without needing GPUs:
     shallow __dict__ copies, EMPTY _parameters, weights re-attached as plain tensor attributes."""

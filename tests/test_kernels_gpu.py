@@ -824,3 +824,29 @@ def test_fused_basic_block_is_race_free_at_full_size():
     for _ in range(6):
         y = ops.conv_block_c64(x, w1, s1, b1, w2, s2, b2, 2)
         assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("who,mode,B,N,has_q,q_lo,q_n", [
+    (False, "softmax", 4, 5, True, 0, 5), (False, "activated", 4, 5, True, 0, 5), (False, "argmax_test", 2, 6, True, 0, 6),
+    (True, "softmax", 4, 5, False, 0, 5), (True, "activated", 3, 5, True, 0, 5),
+    (False, "softmax", 8, 8, True, 3, 2),                   # a rank's query columns over all keys
+    (True, "argmax_test", 2, 16, False, 4, 4),
+])
+def test_comm_graph_fuse_equals_the_two_launches(who, mode, B, N, has_q, q_lo, q_n):
+    """w2c_comm_graph_fuse == w2c_comm_graph_projected + w2c_fuse_values, bit for bit, incl. the packed prob/action/nnz views."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(B * 100 + N)
+    dev = _dev()
+    Dq, C, h, w = 32, 512, 4, 4
+    tproj = torch.randn(N * B, Dq + 1, generator=gen).to(dev)
+    query = (torch.randn(q_n * B, Dq, generator=gen) * 0.7).to(dev) if has_q else None
+    v = torch.randn(N * B, h, w, 2 * C, generator=gen).to(BF16).to(dev)              # value map = first C channels of a wider tensor
+    prob, coef, action, nnz = ops.comm_graph_projected(query, tproj, B, N, who, mode, q_lo=q_lo, q_n=q_n)
+    want = ops.fuse_values(v, C, coef, B, N, q_lo, q_n, append_own=who)
+    got, prob2, coef2, action2, nnz2, pack = ops.comm_graph_fuse(query, tproj, v, C, B, N, who, mode, q_lo=q_lo, q_n=q_n,
+                                                                  append_own=who)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(prob2, prob) and torch.equal(coef2, coef) and torch.equal(action2, action) and torch.equal(nnz2, nnz)
+    p3, a3, n3 = ops.carve_graph_outputs(pack.clone(), B, N, q_n)
+    assert torch.equal(p3, prob) and torch.equal(a3, action) and torch.equal(n3, nnz)
