@@ -417,6 +417,36 @@ def main():
                               if model.use_hip_graph else "eager"),
                   roofline=roofline)
 
+    # ---- scaling efficiency against N = 1, measured in this job (N > 1, or the one-rank proxy --force-sharded) --------------
+    # Every rank times its OWN per-GPU workload as a single-GPU forward (no collectives, one captured graph): for the weak presets
+    # that is exactly what `bench.py --gpus 1` runs, so efficiency_vs_n1 = value / (N * that rate) on the same boxes in the same job;
+    # for the strong presets it is the rank's shard (agents/N agents) alone -- the no-communication bound of the sharded step.
+    if world > 1 or args.force_sharded:
+        n_solo = max(5, args.steps // 2)
+        solo_model = get_model(build_cfg(arch, n_loc, S, preset["query"]), 11)
+        filler.apply_to_module(solo_model)
+        solo_model = solo_model.to(dev).eval()
+        solo_model.use_hip_graph = not args.no_graph
+        _apply_precision(solo_model, args)
+        with torch.no_grad():
+            for _ in range(3):
+                solo_model(x, training=False, MO_flag=True, inference=args.mode)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n_solo):
+                solo_model(x, training=False, MO_flag=True, inference=args.mode)
+            torch.cuda.synchronize(dev)
+            solo_t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(solo_t, op=dist.ReduceOp.MAX)
+        solo_ms = float(solo_t.item()) / n_solo * 1e3
+        n1_value = B * n_loc / (solo_ms * 1e-3)
+        result["efficiency_vs_n1"] = round(value / (world * n1_value), 4)
+        result["n1_reference"] = dict(value=round(n1_value, 2), ms_per_step=round(solo_ms, 4),
+                                      what="each rank's own %d agents x B=%d as an unsharded single-GPU forward in this job "
+                                           "(max over ranks)" % (n_loc, B))
+        del solo_model
+
     # ---- collectives of one step, timed alone (N > 1) ---------------------------------------------
     if world > 1:
         from multiagentperception_amd import parallel as par
