@@ -162,6 +162,12 @@ int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int W, int Cin,
                       uint16_t* idt_bf16, int idt_cstride,
                       const void* zero_page, int variant, w2c_stream_t stream);
 
+/* ---- debug / A-B switches ("W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND", "W2C_STEM_WAVES",
+ * "W2C_WGRAD_PATCH").  The library reads the environment variables of the same names ONCE, when it is loaded; no launch path calls
+ * getenv().  w2c_set_option changes a switch at run time (returns W2C_E_ARG for an unknown name), w2c_get_option reads it (-1 unknown). */
+int w2c_set_option(const char* name, int value);
+int w2c_get_option(const char* name);
+
 /* ---- a whole stride-1 BasicBlock with Cin = Cout = 64 (layer1 of the third-party resnet18, backbone.py:63-69) in ONE launch:
  *   y = relu(bn2(conv2 3x3 (relu(bn1(conv1 3x3 (x))))) + x)
  * The intermediate map never leaves the CU (csrc/conv_block.hip: flattened row strips, x and t in LDS rings, conv1 and conv2 on

@@ -36,6 +36,8 @@ SIGNATURES = {
                            _vp, _i, _vp],
     "w2c_conv_s2_block": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i,
                           _vp, _i, _vp],
+    "w2c_set_option": [_c.c_char_p, _i],
+    "w2c_get_option": [_c.c_char_p],
     "w2c_debug_block_phases": [_vp],
     "w2c_conv_block_c64": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "w2c_conv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
@@ -113,3 +115,10 @@ def check(code, what):
         detail = lib().w2c_last_error_string() if code == -2 else b""
         raise W2CError("%s failed: %s (code %d) %s" % (what, msg.decode() if msg else "?", code,
                                                       detail.decode() if detail else ""))
+
+
+def set_option(name, value):
+    """change a debug / A-B switch of the library at run time (include/w2c_hip.h w2c_set_option); returns the old value"""
+    old = lib().w2c_get_option(name.encode())
+    check(lib().w2c_set_option(name.encode(), int(value)), "w2c_set_option(%s)" % name)
+    return old

@@ -428,8 +428,12 @@ extern "C" int w2c_conv_block_c64(const uint16_t* x, int M, int H, int W, int x_
     a.NT = (64 * (a.L - 1) + 65 + 15) / 16 * 16;
     a.NX = (64 * a.L + 200 + 15) / 16 * 16;
     a.magP = (unsigned)(((1ull << 32) + a.P - 1) / a.P);
-    // timing ablations (debug builds of the kernel, WRONG results): 1 no epilogue, 2 no per-step DMA, 8 no barrier, 16 no fragment reads
+    // timing ablations (-DW2C_BLOCK_ABLATIONS builds only; WRONG results): 1 no epilogue, 2 no per-step DMA, 8 no barrier
+#ifdef W2C_BLOCK_ABLATIONS
     static const int ablate_env = [] { const char* e = getenv("W2C_BLOCK_ABLATE"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int ablate_env = 0;
+#endif
     a.dbg = g_blk_dbg_next;
     g_blk_dbg_next = nullptr;
     static int n_cu[64] = {0};

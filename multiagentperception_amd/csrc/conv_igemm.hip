@@ -32,6 +32,34 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <atomic>
+#include <cstring>
+
+static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH"};
+static std::atomic<int> g_options[W2C_OPT_COUNT];
+static const bool g_options_seeded = [] {
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1};
+    for (int i = 0; i < W2C_OPT_COUNT; ++i) {
+        const char* e = getenv(kOptionNames[i]);            // once, at library load
+        g_options[i].store(e ? atoi(e) : defaults[i]);
+    }
+    return true;
+}();
+int w2c_option(int id) { return (id >= 0 && id < W2C_OPT_COUNT) ? g_options[id].load(std::memory_order_relaxed) : 0; }
+extern "C" int w2c_set_option(const char* name, int value) {
+    if (!name) return W2C_E_ARG;
+    for (int i = 0; i < W2C_OPT_COUNT; ++i)
+        if (!strcmp(name, kOptionNames[i])) { g_options[i].store(value); return W2C_OK; }
+    return W2C_E_ARG;
+}
+extern "C" int w2c_get_option(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < W2C_OPT_COUNT; ++i)
+        if (!strcmp(name, kOptionNames[i])) return g_options[i].load();
+    return -1;
+}
+
 namespace {
 
 struct ConvArgs {
@@ -1548,8 +1576,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
         attr_mask |= 1ull << (dev & 63);
     }
     dim3 grid(a.ntm * a.ntn, groups);
-    const char* const xe = getenv("W2C_XCD2D");                 // (read per launch: tests and tools/ab_xcd2d.sh switch it)
-    const int xcd2d_mode = xe ? atoi(xe) : 1;
+    const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);            // (tests and tools/ab_xcd2d.sh switch it through w2c_set_option)
     // weights of a group larger than half an XCD's L2 and at least as large as its input: split both operands over the XCDs
     const long wbytes = (long)a.Cout * 9 * a.Cin * OpT<F8>::ES, xbytes = (long)a.M * a.H * a.W * a.Cin * OpT<F8>::ES;
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20) && 2 * wbytes >= xbytes)) && groups == 2 && !(a.ntm & 1) &&
@@ -1755,7 +1782,7 @@ int pick_variant_f8(const ConvArgs& a, int groups) {
     const long rows = a.rows;
     const int Cout = a.Cout;
     if (a.stride == 2 && a.ks == 3 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && Cout % 64 == 0 && !(a.H & 1) && !(a.W & 1) && !a.res &&
-        !getenv("W2C_NO_S2PATCH"))
+        !w2c_option(W2C_OPT_NO_S2PATCH))
         return 60;
     if (a.ks == 3 && a.stride == 1 && a.H % 8 == 0 && a.W % 16 == 0) {
         const long tiles = (long)a.M * (a.H / 8) * (a.W / 16) * groups;
@@ -1792,7 +1819,7 @@ int pick_variant(const ConvArgs& a, int groups) {
         if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;
     }
     if (a.stride == 2 && a.ks == 3 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && Cout % 64 == 0 && !(a.H & 1) && !(a.W & 1) && !a.ws &&
-        !a.res && !getenv("W2C_NO_S2PATCH"))
+        !a.res && !w2c_option(W2C_OPT_NO_S2PATCH))
         return 60;
     // stride-2 3x3: the 128x64 tile beats 128x128 at every cfg-2 shape (tools/bench_s2_block.py: 46.1 / 36.9 / 36.5 us vs
     // 47.7 / 42.8 / 38.1 us) -- twice the workgroups for a kernel whose K-step is dominated by the 9x re-gather of its rows
@@ -1954,7 +1981,7 @@ extern "C" int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int 
     // maps that tile into 8 x 16 output pixels go to the polyphase halo-patch kernel (variant 60), the rest to the generic
     // DUAL kernel; both walk K in the same order, so the choice never shows in the bits
     const bool patch_ok = a.Ho % 8 == 0 && a.Wo % 16 == 0 && Cout % 64 == 0 && !(H & 1) && !(W & 1);
-    if (variant == 60 || (variant < 0 && patch_ok && !getenv("W2C_NO_S2PATCH")))
+    if (variant == 60 || (variant < 0 && patch_ok && !w2c_option(W2C_OPT_NO_S2PATCH)))
         return x_is_fp8 ? launch_s2patch<64, 3, true>(a, groups, s) : launch_s2patch<64, 3, false>(a, groups, s);
     if (variant == 61) return x_is_fp8 ? launch_s2patch<128, 2, true>(a, groups, s) : launch_s2patch<128, 2, false>(a, groups, s);
     if (variant == 62) return x_is_fp8 ? launch_s2patch<64, 2, true>(a, groups, s) : launch_s2patch<64, 2, false>(a, groups, s);

@@ -411,8 +411,7 @@ static int wgrad_impl(const uint16_t* x, int M, int H, int W, int Cin, int x_cst
     a.nct_o = Cout / 64; a.nct_i = Cin / 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.nct_o * a.nct_i, a.nseg, groups);
-    const char* const pe = getenv("W2C_WGRAD_PATCH");
-    if (ksize == 3 && stride == 1 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && !(pe && atoi(pe) == 0)) {
+    if (ksize == 3 && stride == 1 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && w2c_option(W2C_OPT_WGRAD_PATCH) != 0) {
         constexpr int lds = 2 * (23 * 1024 + 128 * 128);
         static unsigned long long attr_mask = 0;
         int dev = 0;

@@ -1202,7 +1202,7 @@ static int launch_stem_pool3(const void* x, FrameMean mean, int B, int N, int H,
     }
     const int total = N * B * ((H / 2) / 8) * ((W / 2) / 32);
     int wgs = n_cu[dev & 63];
-    if (const char* e = getenv("W2C_STEM_WGS")) { const int v = atoi(e); if (v > 0) wgs = v; }   // tests: odd runs, mid-band starts
+    if (const int v = w2c_option(W2C_OPT_STEM_WGS); v > 0) wgs = v;                             // tests: odd runs, mid-band starts
     int spw = (total + wgs - 1) / wgs;
     if (spw < 2) spw = 2;                                      // both groups busy
     wgs = (total + spw - 1) / spw;
@@ -1213,7 +1213,7 @@ static int launch_stem_pool3(const void* x, FrameMean mean, int B, int N, int H,
 template <int COUT, bool U8>
 static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                             const float* shift, uint16_t* y, hipStream_t s) {
-    static const int band = [] { const char* e = getenv("W2C_STEM_BAND"); return e ? atoi(e) : 8; }();
+    const int band = w2c_option(W2C_OPT_STEM_BAND);
     // measured (tools/bench_stem.py, cfg 2): BAND 8 143 us, BAND 4 154 us -- the second resident workgroup does not pay
     // for its 5/4 recompute; W2C_STEM_BAND=4 keeps the A/B reproducible.
     // 12 waves (conv rows split 3/3/3 instead of 4/5): measured 159 us vs 145 us for 8 waves -- kept for the A/B only
@@ -1222,14 +1222,14 @@ static int launch_stem_pool(const void* x, FrameMean mean, int B, int N, int H, 
     // SIMD overlap 1.5x).  Cout = 64 (Single_agent): the LDS-pooling form is faster (95 vs 104 us).  W2C_STEM_FORM=1|2 forces.
     // Measured and dropped: a 3-waves/SIMD build (4 accumulation passes, 168 registers: 40 spilled dwords -> 186 us), 4-row
     // bands for a finer tail (1280 half-size workgroups: 112 us), staggered starts of co-resident workgroups (no change).
-    const int form = [] { const char* e = getenv("W2C_STEM_FORM"); return e ? atoi(e) : 0; }();      // (read per launch: tests switch it)
+    const int form = w2c_option(W2C_OPT_STEM_FORM);
     // Cout = 128 default: the persistent ping-pong form (100.7 vs 106.9 us for form 2 at cfg 2)
     if constexpr (COUT == 128) {
         if ((form == 3 || form == 0) && H % 16 == 0) return launch_stem_pool3<U8>(x, mean, B, N, H, W, w, scale, shift, y, s);
     }
     if ((form == 2 || (form == 0 && COUT == 128)) && H % 16 == 0)
         return launch_stem_pool2<COUT, U8>(x, mean, B, N, H, W, w, scale, shift, y, s);
-    static const int nw = [] { const char* e = getenv("W2C_STEM_WAVES"); return e ? atoi(e) : 8; }();
+    const int nw = w2c_option(W2C_OPT_STEM_WAVES);
     if (band == 4) return launch_stem_pool_band<COUT, U8, 4, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);
     if (nw == 12 && COUT == 128) return launch_stem_pool_band<COUT, U8, 8, (COUT == 128 ? 12 : 8)>(x, mean, B, N, H, W, w, scale, shift, y, s);
     return launch_stem_pool_band<COUT, U8, 8, 8>(x, mean, B, N, H, W, w, scale, shift, y, s);

@@ -77,3 +77,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + loc;
 }
+
+// Debug / A-B switches.  The launch paths never call getenv(): the table is seeded from the environment ONCE, when the library is
+// loaded, and changed at run time through the C ABI (w2c_set_option; tests and tools/ use that).  Defined in conv_igemm.hip.
+enum W2COption {
+    W2C_OPT_XCD2D = 0,        // 0 off | 1 auto (default) | 2 force: XCD-aware 2-D tile placement of two-group patch launches
+    W2C_OPT_NO_S2PATCH,       // 1: stride-2 block fronts on the generic kernels instead of the polyphase patch kernel
+    W2C_OPT_STEM_WGS,         // > 0: workgroup count of the ping-pong stem (tests: odd run lengths)
+    W2C_OPT_STEM_FORM,        // 0 auto | 1 | 2 | 3: stem kernel form
+    W2C_OPT_STEM_BAND,        // 8 (default) | 4
+    W2C_OPT_STEM_WAVES,       // 8 (default) | 12
+    W2C_OPT_WGRAD_PATCH,      // 1 (default) | 0: halo-patch weight-gradient kernel
+    W2C_OPT_COUNT
+};
+int w2c_option(int id);

@@ -167,6 +167,10 @@ class TrunkPlan:
         self.G = len(encoders)
         self.n8 = 0 if precision == "bf16" else (1 if precision == "fp8" else self.G)     # leading trunks that run in fp8
         self._encoders = encoders if self.n8 else None
+        self._enc_all = encoders
+        # block index (2, 4 or 6: a stride-2 block) from which the two trunks run as separate launch chains on two streams
+        sf_env = os.environ.get("W2C_SPLIT_TRUNKS")
+        self.split_from = (int(sf_env) if sf_env != "-1" else None) if sf_env not in (None, "") else 2
         fbs = [e.feature_backbone.feature_backbone for e in encoders]
         # stem: [Cout][7][8][4] bf16, kx==7 / ci==3 zero
         ws, scs, shs = [], [], []
@@ -201,7 +205,7 @@ class TrunkPlan:
             return ops.stem_u8_conv7x7_bn_relu_maxpool(x, self.stem_w, self.stem_scale, self.stem_shift, out=out)
         return ops.stem_conv7x7_bn_relu_maxpool(x, n_agents, self.stem_w, self.stem_scale, self.stem_shift, out=out)
 
-    def after_stem(self, p, squeezer_out=None):
+    def after_stem(self, p, squeezer_out=None, policy_next=None):
         """layer1..4 + squeezers on the pooled stem output -> bf16 NHWC [N*B, H/32, W/32, G*feat]; with
         squeezer_out = one [N*B, H/32, W/32, feat] tensor per trunk, each squeezer writes its own (the agent-parallel
         path: V lands in the rank's slot of the all-gather buffer) and the list is returned."""
@@ -212,10 +216,72 @@ class TrunkPlan:
         # (Measured and rejected, profiles/r02_concurrency_experiments.txt: the 1x1/s2 downsample on a side stream beside
         # conv1 (-1 %), and the batch cut into 2-3 slices on parallel streams to fill the workgroup-quantisation tails
         # (-9..-15 %): full-size bf16 launches leave no room for a second kernel.)
-        for c1, c2, ds in self.blocks:
+        split_from = self.split_from
+        if split_from is None or self.G != 2:
+            for c1, c2, ds in self.blocks:
+                t, idt = _block_front(c1, ds, p)
+                p = c2.run(t, residual=idt)
+            res = self.squeezer.run(p, out_groups=squeezer_out)
+            if policy_next is not None:
+                return res, policy_next[1](policy_next[0](res if squeezer_out is None else res[1]))
+            return res
+        # From block `split_from` (a stride-2 block) on, the two trunks run as two independent chains of ONE-group launches on two
+        # streams (parallel branches under graph capture).  A two-group launch of a deep layer is a non-integer number of
+        # workgroup rounds (layer4 / squeezers: 640 workgroups on 512 slots = 1.25 rounds, paid as 2); two independent chains have
+        # no round boundary in common, so one chain's next launch fills the slots the other's tail leaves idle.  Same kernels,
+        # same bits (results do not depend on the group count).
+        for c1, c2, ds in self.blocks[:split_from]:
             t, idt = _block_front(c1, ds, p)
             p = c2.run(t, residual=idt)
-        return self.squeezer.run(p, out_groups=squeezer_out)
+        plans = self._single_trunk_plans(split_from)
+        cin0 = self.blocks[split_from][0].cin
+        feat = self.squeezer.cout
+        M, Hs, Ws, _ = p.shape
+        for _, _, ds in self.blocks[split_from:]:
+            if ds is not None:
+                Hs, Ws = (Hs + 1) // 2, (Ws + 1) // 2
+        sq = None if squeezer_out is not None else torch.empty((M, Hs, Ws, self.G * feat), dtype=BF16, device=p.device)
+        main = torch.cuda.current_stream(p.device)
+        side = self._side_stream(p.device)
+        side.wait_stream(main)
+
+        def chain(g):
+            q, off = p, g * cin0
+            for c1, c2, ds in plans[g][0]:
+                t, idt = _block_front(c1, ds, q, x_ch_off=off)       # the chain's first block is a stride-2 block: idt is its own
+                q, off = c2.run(t, residual=idt), 0
+            if squeezer_out is not None:
+                plans[g][1].run(q, out_groups=[squeezer_out[g]])
+            else:
+                plans[g][1].run(q, out=sq, out_ch_off=g * feat)
+
+        state = None
+        with torch.cuda.stream(side):
+            chain(1)
+            if policy_next is not None:            # the policy chain goes straight on (policy convs) beside the value chain
+                state = policy_next[0](sq if squeezer_out is None else squeezer_out[1])
+        chain(0)
+        main.wait_stream(side)
+        extra = policy_next[1](state) if policy_next is not None else None
+        res = list(squeezer_out) if squeezer_out is not None else sq
+        return (res, extra) if policy_next is not None else res
+
+    def _single_trunk_plans(self, split_from):
+        key = ("single", split_from)
+        cache = self.__dict__.setdefault("_plan_cache", {})
+        if key not in cache:
+            out = []
+            for e in self._enc_all:
+                fb = e.feature_backbone.feature_backbone
+                blocks = []
+                for bi in range(split_from, 8):
+                    b = getattr(fb, "layer%d" % (bi // 2 + 1))[bi % 2]
+                    blocks.append((ConvPlan([b.conv1], [b.bn1], relu=True), ConvPlan([b.conv2], [b.bn2], relu=True),
+                                   None if b.downsample is None else ConvPlan([b.downsample[0]], [b.downsample[1]], relu=False)))
+                u = e.squeezer.cbr_unit
+                out.append((blocks, ConvPlan([u[0]], [u[1]], relu=True)))
+            cache[key] = out
+        return cache[key]
 
     # ---- fp8 trunk (cfg 5) ------------------------------------------------------------------------------------------
     def calibrate(self, p, reduce_amax=None):
@@ -301,7 +367,7 @@ class TrunkPlan:
     def _side_stream(self, dev):
         st = self.__dict__.setdefault("_side", {})
         if dev not in st:
-            st[dev] = torch.cuda.Stream(device=dev)
+            st[dev] = torch.cuda.Stream(device=dev)      # (a high-priority side stream measured 2.3 ms per forward instead of 1.25)
         return st[dev]
 
     def _rest_bf16(self, p, sq, squeezer_out, feat):
@@ -332,11 +398,15 @@ class HeadPlan:
         """key_projection = (Wq [Dk,Dq], bq [Dk]) folds the attention's query projection into the FIRST head's
         (the key head's) last layer: it then emits tproj = [(Wq^T W4) h1 + Wq^T b4 | (bq^T W4) h1 + bq.b4]
         (Dq+1 values) instead of the Dk-wide key -- exactly what w2c_comm_graph_projected consumes."""
+        # Packed ON THE HOST (float64 where it matters) and uploaded with synchronous copies: the plan is built lazily, possibly on a
+        # side stream next to other work, and the device-side float64 matmuls this used to run (rocBLAS, first use of a handle on a
+        # fresh stream) were seen delivering the folded key projection after its first consumer had already run.
+        dev = heads[0].fc[0].weight.device
         w0s, b0s = [], []
         self.tails = []
         for hi, head in enumerate(heads):
             fc = head.fc
-            w0 = fc[0].weight.detach().float()
+            w0 = fc[0].weight.detach().float().cpu()
             n_feat = w0.shape[1]
             if hw <= 0 or n_feat % hw != 0:
                 raise ops.W2CError("head: fc.0 expects %d features, the policy map has %d pixels (input resolution does not "
@@ -344,17 +414,17 @@ class HeadPlan:
                                    % (n_feat, hw))
             c = n_feat // hw
             w0s.append(w0.reshape(w0.shape[0], c, hw).permute(0, 2, 1).reshape(w0.shape[0], n_feat))
-            b0s.append(fc[0].bias.detach().float())
-            w4, b4 = fc[4].weight.detach().double(), fc[4].bias.detach().double()
+            b0s.append(fc[0].bias.detach().float().cpu())
+            w4, b4 = fc[4].weight.detach().double().cpu(), fc[4].bias.detach().double().cpu()
             if hi == 0 and key_projection is not None:
-                wq, bq = key_projection[0].detach().double(), key_projection[1].detach().double()
+                wq, bq = key_projection[0].detach().double().cpu(), key_projection[1].detach().double().cpu()
                 w4 = torch.cat([wq.t() @ w4, (bq @ w4).unsqueeze(0)], 0)            # [Dq+1, 128]
                 b4 = torch.cat([wq.t() @ b4, (bq @ b4).reshape(1)])                  # [Dq+1]
-            self.tails.append((w0.shape[0], fc[2].weight.detach().float().t().contiguous(),
-                               fc[2].bias.detach().float().contiguous(),
-                               w4.float().t().contiguous(), b4.float().contiguous()))
-        self.w0 = torch.cat(w0s, 0).contiguous()
-        self.b0 = torch.cat(b0s).contiguous()
+            self.tails.append((w0.shape[0], fc[2].weight.detach().float().cpu().t().contiguous().to(dev),
+                               fc[2].bias.detach().float().cpu().contiguous().to(dev),
+                               w4.float().t().contiguous().to(dev), b4.float().contiguous().to(dev)))
+        self.w0 = torch.cat(w0s, 0).contiguous().to(dev)
+        self.b0 = torch.cat(b0s).contiguous().to(dev)
         self.n_feat = n_feat
 
     def run(self, qk_map, outs=None):
@@ -419,13 +489,15 @@ class CommEngine:
     def _head_plan(self, y):
         """HeadPlan for policy map y [M,h,w,256]; raises (like the reference's view(-1, n_feat)) when h*w*256 is not
         what fc.0 was built for."""
-        hw = y.shape[1] * y.shape[2]
+        return self._head_plan_hw(y.shape[1] * y.shape[2], y.shape[3], tuple(y.shape))
+
+    def _head_plan_hw(self, hw, ch, shape=None):
         plan = self._heads.get(hw)
         if plan is None:
             n_feat = self._model_heads[0].fc[0].in_features
-            if hw * y.shape[3] != n_feat:
+            if hw * ch != n_feat:
                 raise ops.W2CError("policy map %s has %d features, the key/query heads expect %d: input resolution does not "
-                                   "match the model's image_size" % (tuple(y.shape), hw * y.shape[3], n_feat))
+                                   "match the model's image_size" % (shape if shape is not None else (hw, ch), hw * ch, n_feat))
             plan = HeadPlan([h for h in self._model_heads if h is not None], hw, key_projection=(self.wq, self.bq))
             self._heads[hw] = plan
         return plan
@@ -435,9 +507,15 @@ class CommEngine:
         by default its second half (agent.py:137-141, 1126-1129) -> PROJECTED keys tproj f32 [n*B,Dq+1] (the
         attention's Linear(query) folded into the key head, see HeadPlan), queries f32 [n*B,Dq] or None.
         outs = preallocated (tproj, queries)."""
+        return self.policy_heads(self.policy_convs(sq, ch_off), outs)
+
+    def policy_convs(self, sq, ch_off=None):
         y = self.policy[0].run(sq, x_ch_off=self.feat if ch_off is None else ch_off)
         for c in self.policy[1:]:
             y = c.run(y)
+        return y
+
+    def policy_heads(self, y, outs=None):
         res = self._head_plan(y).run(y, outs=outs)
         return res[0], (res[1] if len(res) > 1 else None)
 
@@ -453,8 +531,15 @@ class CommEngine:
         (Measured and rejected, profiles/r02_concurrency_experiments.txt: running the policy encoder's layer4 alone first so
         that the policy tail overlaps the value encoder's layer4 on a second stream -- 1.2988 vs 1.3024 ms, no gain: the
         tail's launches are inefficient, not idle, and a concurrent kernel only shares their CUs.)"""
-        sq = self.trunk.after_stem(s0)
-        keys, querys = self.policy_tail(sq)
+        if self.trunk.n8 or os.environ.get("W2C_NO_TAIL_OVERLAP"):
+            sq = self.trunk.after_stem(s0)
+            keys, querys = self.policy_tail(sq)
+            return sq, keys, querys
+        # The policy chain's side stream carries on with policy conv1..5 beside the value chain; the HEADS run after the join, on
+        # the forward's own stream.  (With the heads on the side stream too, the first forward of a process delivered a few stale
+        # rows of fc.0's input to w2c_linear_f32 in 5 of 8 processes -- tools/stress_first_forward.py, profiles/r03_concurrency.txt --
+        # although every producer was on the same stream; conv -> conv hand-offs on the side stream never showed it.)
+        sq, (keys, querys) = self.trunk.after_stem(s0, policy_next=(self.policy_convs, self.policy_heads))
         return sq, keys, querys
 
     def graph_and_low(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
@@ -554,6 +639,7 @@ class SRMSEngine:
 
     N = 5
     _head_plan = CommEngine._head_plan
+    _head_plan_hw = CommEngine._head_plan_hw
 
     def __init__(self, model):
         self.who = bool(model._who)

@@ -146,17 +146,23 @@ def maxpool3x3s2(x, out=None):
 
 
 _splitk_ws = {}
+_SPLITK_WS_MAX = 16            # (device, stream) entries kept; the least recently used one goes first
 
 
 def splitk_workspace(dev, nbytes):
     """Split-K scratch, one per (device, stream): launches that share a workspace are ordered by the stream they run on,
     so concurrent streams / DataParallel replica threads / a graph under capture never share one.  Contents are
-    irrelevant to the kernel (every partial tile is written before it is read)."""
+    irrelevant to the kernel (every partial tile is written before it is read).  The cache is BOUNDED (a process that keeps
+    creating streams would otherwise pin 16 MiB per stream forever): least recently used entries are dropped -- the caching
+    allocator keeps a dropped block alive until the launches already queued on its stream have run, and a captured graph holds
+    its own reference to the block it was captured with."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
-    ws = _splitk_ws.get(key)
+    ws = _splitk_ws.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 16 << 20), dtype=torch.uint8, device=dev)
-        _splitk_ws[key] = ws
+    _splitk_ws[key] = ws                                   # (re)insert as most recently used
+    while len(_splitk_ws) > _SPLITK_WS_MAX:
+        _splitk_ws.pop(next(iter(_splitk_ws)))
     return ws
 
 
@@ -200,7 +206,7 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
     if out_cstride is None:
-        out_cstride = groups * cout
+        out_cstride = out.shape[3] if (out is not None and out.dim() == 4) else groups * cout
     if out_ch_off:                                   # write channels [out_ch_off, +groups*cout) of a wider `out` tensor
         if out is None or residual is not None or out_ch_off < 0 or out_ch_off % 8 or out_ch_off + groups * cout > out.shape[3]:
             raise W2CError("conv: out_ch_off needs an `out` tensor wide enough, no residual, a multiple of 8")

@@ -422,3 +422,19 @@ def test_miou_within_a_tenth_of_a_point_of_the_reference_on_scenes(name, arch, n
     # and label map against label map: per-class agreement in points
     agree_pts = 100.0 * orc.mean_iou(orc.confusion_matrix(ref.argmax(1).numpy(), pred.argmax(1).numpy()))
     assert agree_pts >= 99.0, (name, agree_pts)
+
+
+def test_first_forward_of_a_process_is_deterministic_under_the_concurrent_launch_chains():
+    """The two trunks run as concurrent one-group launch chains on two streams and the policy convs overlap the value chain
+    (engine.TrunkPlan.after_stem).  tools/stress_first_forward.py builds a fresh model per iteration and compares its FIRST forward
+    bit for bit with the first model's; run in fresh processes, because the one hazard this scheme ever showed (heads on the
+    side stream: profiles/r03_concurrency.txt) only hit the first forward of a process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for arch, n, b in (("MIMOcom", 8, 8), ("MIMOcomWho", 5, 4)):
+        for _ in range(3):
+            out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_first_forward.py"), arch, str(n), str(b), "512", "4"],
+                                 capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-2000:]
+            assert ": 0 / 3 first forwards differ" in out.stdout, out.stdout[-2000:]

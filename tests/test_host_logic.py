@@ -226,6 +226,7 @@ def test_head_plan_rejects_a_resolution_the_model_was_not_built_for():
         wq = torch.zeros(1024, 32)
         bq = torch.zeros(1024)
         _head_plan = engine.CommEngine._head_plan
+        _head_plan_hw = engine.CommEngine._head_plan_hw
     with pytest.raises(W2CError, match="image_size"):
         _Eng()._head_plan(torch.zeros(2, 2, 2, 256))                      # a 256^2 frame through a 128^2 model
     assert _Eng()._head_plan(torch.zeros(2, 1, 1, 256)).n_feat == 256

@@ -16,6 +16,21 @@ pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
 
 
+@pytest.fixture
+def lib_option():
+    """set a library debug switch for the duration of a test (include/w2c_hip.h w2c_set_option; the library reads the environment
+    only once, at load time)"""
+    from multiagentperception_amd import _native
+    changed = {}
+
+    def setter(name, value):
+        old = _native.set_option(name, value)
+        changed.setdefault(name, old)
+    yield setter
+    for name, old in changed.items():
+        _native.set_option(name, old)
+
+
 def _dev():
     assert torch.cuda.is_available(), "gpu tests need an MI355X"
     return torch.device("cuda:0")
@@ -279,7 +294,7 @@ def test_conv_result_is_independent_of_tile_variant_and_image_count(cin, cout, h
 
 
 @pytest.mark.parametrize("cin,cout,hw,M", [(512, 512, 16, 20), (256, 256, 16, 6), (128, 128, 32, 2)])
-def test_xcd_tile_placement_does_not_change_results(cin, cout, hw, M, monkeypatch):
+def test_xcd_tile_placement_does_not_change_results(cin, cout, hw, M, lib_option):
     """Two-group patch launches place their tiles per XCD (group, half the spatial tiles, half the channel tiles) when the
     weights dominate; placement is speed only: forced off (0), heuristic (1) and forced on (2) give identical bits."""
     from multiagentperception_amd import ops
@@ -292,7 +307,7 @@ def test_xcd_tile_placement_does_not_change_results(cin, cout, hw, M, monkeypatc
     res = torch.randn(M, hw, hw, G * cout, generator=gen).to(BF16).to(_dev())
     outs = {}
     for mode in ("0", "1", "2"):
-        monkeypatch.setenv("W2C_XCD2D", mode)
+        lib_option("W2C_XCD2D", int(mode))
         for v in (30, 36):
             outs[(mode, v)] = ops.conv_igemm(x, 0, cin, w, cout, 3, 1, G, sc, sh, residual=res, variant=v)
     torch.cuda.synchronize()
@@ -346,7 +361,7 @@ def test_fused_stem_maxpool_equals_unfused_bit_for_bit(cout, B, N, H, W):
 
 
 @pytest.mark.parametrize("wgs", [1, 3, 5, 7, 11, 48])
-def test_pingpong_stem_runs_of_any_length_and_start(wgs, monkeypatch):
+def test_pingpong_stem_runs_of_any_length_and_start(wgs, lib_option):
     """The persistent ping-pong stem (third form) with its workgroup count forced: runs of odd and even length, runs that start
     inside a band (an unstored warm-up step supplies the carried column) and runs that cross bands and images."""
     from multiagentperception_amd import ops
@@ -361,7 +376,7 @@ def test_pingpong_stem_runs_of_any_length_and_start(wgs, monkeypatch):
     scale = scale.to(_dev())
     shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
     ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
-    monkeypatch.setenv("W2C_STEM_WGS", str(wgs))
+    lib_option("W2C_STEM_WGS", wgs)
     got = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
@@ -734,7 +749,7 @@ def test_stride2_patch_pipeline_is_race_free_under_full_occupancy(variant, cin, 
 
 
 @pytest.mark.parametrize("wgs", [64, 256, 300])
-def test_pingpong_stem_is_race_free_over_repeated_launches(wgs, monkeypatch):
+def test_pingpong_stem_is_race_free_over_repeated_launches(wgs, lib_option):
     """Persistent ping-pong stem at a 4-image 512x512 batch with 64 / 256 / 300 workgroups (runs of 16, 4 and 3-4 steps; three
     rotating patch buffers, barrier-separated slots): 12 launches each, all bit-identical to the unfused reference."""
     from multiagentperception_amd import ops
@@ -747,7 +762,7 @@ def test_pingpong_stem_is_race_free_over_repeated_launches(wgs, monkeypatch):
     scale = (torch.rand(cout, generator=gen) + 0.5).to(_dev())
     shift = (torch.randn(cout, generator=gen) * 0.3).to(_dev())
     ref = ops.maxpool3x3s2(ops.stem_conv7x7_bn_relu(x, N, w, scale, shift))
-    monkeypatch.setenv("W2C_STEM_WGS", str(wgs))
+    lib_option("W2C_STEM_WGS", wgs)
     for _ in range(12):
         got = ops.stem_conv7x7_bn_relu_maxpool(x, N, w, scale, shift)
         torch.cuda.synchronize()

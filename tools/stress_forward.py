@@ -1,0 +1,39 @@
+"""Determinism stress of the whole eval forward (the two trunks run as concurrent launch chains): N forwards of the same input must be
+bit-identical.  python tools/stress_forward.py [arch agents batch size iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multiagentperception_amd import synth as filler  # noqa: E402
+from ptsemseg.models import get_model  # noqa: E402
+
+arch, n, b, size, iters = (sys.argv[1:6] + [None] * 5)[:5]
+arch = arch or "MIMOcom"
+n, b, size, iters = int(n or 5), int(b or 4), int(size or 512), int(iters or 40)
+has_query = arch != "MIMOcomWho"
+model = dict(arch=arch, agent_num=n, shared_img_encoder="unified", attention="general", sparse=False, query=has_query, query_size=32,
+             key_size=1024, enc_backbone="resnet_encoder", dec_backbone="simple_decoder", feat_squeezer=-1, feat_channel=512)
+m = get_model({"model": model, "data": {"img_rows": size, "img_cols": size}}, 11)
+filler.apply_to_module(m)
+m = m.to("cuda:0").eval()
+m.use_hip_graph = bool(int(os.environ.get("STRESS_GRAPH", "0")))
+x = torch.from_numpy(filler.synthetic_frames(b, n, size, size, 77)).cuda()
+junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+ref = None
+bad = 0
+for i in range(iters):
+    if i % 3 == 1:
+        junk.random_()                      # allocator churn / other traffic between forwards
+    out = m(x, training=False, MO_flag=True, inference="softmax")
+    torch.cuda.synchronize()
+    cur = (out[0].clone(), out[1].clone())
+    if ref is None:
+        ref = cur
+    elif not (torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])):
+        bad += 1
+        print("iter %d differs: P max diff %.3e logits max diff %.3e" % (i, float((cur[1] - ref[1]).abs().max()),
+                                                                          float((cur[0] - ref[0]).abs().max())), flush=True)
+print("%s n%d b%d %d graph=%s split=%s notail=%s: %d / %d forwards differ from the first" % (
+    arch, n, b, size, m.use_hip_graph, os.environ.get("W2C_SPLIT_TRUNKS"), os.environ.get("W2C_NO_TAIL_OVERLAP"), bad, iters - 1))
