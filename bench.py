@@ -382,10 +382,12 @@ def main():
     model.use_hip_graph = not args.no_graph
     conv_ms, conv_fl, launches, per_shape = timer.summary()
     conv_bytes = timer.algorithmic_bytes() / reps
+    busy_ms = timer.busy_ms() / reps                 # union of the launch intervals: the two trunk chains overlap (two streams)
     conv_ms /= reps
     conv_fl /= reps
     launches //= reps
-    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    achieved = conv_fl / (busy_ms * 1e-3) / 1e12 if busy_ms > 0 else 0.0
+    achieved_sum = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     flop_per_img = GFLOP_PER_AGENT_IMAGE_512[arch] * (S / 512.0) ** 2
     peak = PEAK_BF16_TFLOPS
     layers = []
@@ -395,7 +397,11 @@ def main():
                            tflops=round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0))
     roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16", achieved=round(achieved, 2), peak=peak,
                     unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
-                    launches_per_step=launches, kernel_ms_per_step=round(conv_ms, 4),
+                    launches_per_step=launches, kernel_ms_per_step=round(busy_ms, 4),
+                    kernel_ms_sum_of_durations=round(conv_ms, 4), frac_by_sum_of_durations=round(achieved_sum / peak, 4),
+                    time_note="launches of the value and the policy trunk overlap on two streams from layer2 on: kernel_ms_per_step "
+                              "and frac use the UNION of the launch intervals (chip time spent in the family); the sum of the "
+                              "per-launch durations counts shared wall time twice and is given beside it",
                     algorithmic_gflop_per_step=round(conv_fl / 1e9, 2),
                     algorithmic_bytes_per_step=int(conv_bytes),
                     whole_forward_tflops=round(value * flop_per_img / 1e3, 2),

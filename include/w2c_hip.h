@@ -241,6 +241,8 @@ int w2c_debug_fp8_pack(const float* x, uint8_t* y, int n, w2c_stream_t stream);
  * 4 x uint64 wall-clock stamps per workgroup (start, first tile landed, main loop done, end; 100 MHz) into buf
  * (device memory, >= 32 bytes x workgroups). */
 int w2c_debug_conv_timeline(void* buf);
+/* Debug: enqueue a one-thread kernel that writes the 100 MHz wall clock to *slot (u64): a time stamp in stream order. */
+int w2c_debug_stamp(void* slot, w2c_stream_t stream);
 
 /* ---- K5: Linear (+ReLU) for the key/query heads (agent.py:150-159,167-178).
  * x : [M, K] bf16 (x_is_bf16=1, row stride x_stride elements) or f32

@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -1593,32 +1593,12 @@ constexpr int conv_lds_bytes() {
     return ring > epi ? ring : epi;
 }
 
-// Second half of a split-K conv: out = act(scale * sum_z partial_z + shift (+ residual)); one thread per 8 channels.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
-    constexpr int CG = BN / 8;
-    const int g = blockIdx.y;
-    const long total = (long)p.ntm * p.ntn * BM * CG;
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= total) return;
-    const int cg = (int)(id % CG);
-    const long t1 = id / CG;
-    const int r = (int)(t1 % BM);
-    const int tile = (int)(t1 / BM);                         // == xcd_remap'ed tile id used by the producer
-    const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-    const int gr = tm * BM + r;
-    if (gr >= p.rows) return;
-    const float* sp = p.ws + (((size_t)g * (p.ntm * p.ntn) + tile) * p.n_split) * (size_t)(BM * BN) + r * BN + cg * 8;
-    f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    for (int z = 0; z < p.n_split; ++z) {
-        v0 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN));
-        v1 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN) + 4);
-    }
-    const int ch = g * p.Cout + tn * BN + cg * 8;
+// The epilogue of a split-K conv on the summed partials of 8 consecutive channels of one pixel: BN scale/shift (+ residual) (+ ReLU),
+// store.  ONE body for the finish kernel and the in-workgroup form: the two must round alike.
+__device__ __forceinline__ void splitk_epilogue8(const ConvArgs& p, f32x4_t v0, f32x4_t v1, int ch, size_t off) {
     v0 = v0 * *reinterpret_cast<const f32x4_t*>(p.scale + ch) + *reinterpret_cast<const f32x4_t*>(p.shift + ch);
     v1 = v1 * *reinterpret_cast<const f32x4_t*>(p.scale + ch + 4) + *reinterpret_cast<const f32x4_t*>(p.shift + ch + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const size_t off = (size_t)gr * p.ycs + (size_t)g * p.ygs + tn * BN + cg * 8;
     if (p.res) {
         const uint4 rr = *reinterpret_cast<const uint4*>(p.res + off);
         const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -1642,6 +1622,186 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + off) = o;
     }
+}
+
+// Second half of a split-K conv: out = act(scale * sum_z partial_z + shift (+ residual)); one thread per 8 channels.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
+    constexpr int CG = BN / 8;
+    const int g = blockIdx.y;
+    const long total = (long)p.ntm * p.ntn * BM * CG;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int cg = (int)(id % CG);
+    const long t1 = id / CG;
+    const int r = (int)(t1 % BM);
+    const int tile = (int)(t1 / BM);                         // == xcd_remap'ed tile id used by the producer
+    const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+    const int gr = tm * BM + r;
+    if (gr >= p.rows) return;
+    const float* sp = p.ws + (((size_t)g * (p.ntm * p.ntn) + tile) * p.n_split) * (size_t)(BM * BN) + r * BN + cg * 8;
+    f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    for (int z = 0; z < p.n_split; ++z) {
+        v0 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN));
+        v1 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN) + 4);
+    }
+    splitk_epilogue8(p, v0, v1, g * p.Cout + tn * BN + cg * 8, (size_t)gr * p.ycs + (size_t)g * p.ygs + tn * BN + cg * 8);
+}
+
+// Split-K INSIDE one workgroup, for the tail layers (policy conv2..5, the decoder's last 3x3: <= 1280 output rows under a
+// 2304-long K): wave z of the workgroup is split z of the split-K launch above -- the same K-step range [z kt / S, (z+1) kt / S), the
+// same MFMA sequence per 32x32 block -- and the S partial tiles meet in LDS instead of an f32 workspace in HBM, where 256 threads add
+// them in split order and run the finish kernel's epilogue.  One launch instead of two, no workspace round trip, and bit-identical
+// to the two-launch form (same products, same order of additions).  Operands go global -> VGPR fragments directly (the 16 bytes a
+// lane feeds the MFMA are 16 contiguous bytes of one pixel / one filter row): with 3..5 K-steps per wave there is no ring to
+// amortise, only latency to overlap -- all loads of K-step t+1 are in flight under the MFMAs of K-step t.
+// Tile = BM_ x 32 outputs, LDS = S x BM_ x 36 x 4 bytes, kept under 80 KB so that the workgroup fits beside ONE workgroup of the
+// other launch chain's conv kernels on a CU (they take 68..79 KB each): a bigger footprint would wait for a fully drained CU.
+template <int BM_, int UF, int MAXT>
+__global__ __launch_bounds__(MAXT) void conv_inwg_splitk_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BN_ = 32, MI = BM_ / 32, CLD = BN_ + 4, CG = BN_ / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const part = reinterpret_cast<float*>(smem);          // [split][BM_][CLD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int z = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_split = p.n_split;
+    const int g = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)g * p.Cin * 2;
+    const int Ktot = p.ktiles * 64;
+    const char* wg = reinterpret_cast<const char*>(p.w) + (size_t)g * p.Cout * Ktot * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(xg), 0, (int)((size_t)p.M * p.H * p.W * p.xcs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wg), 0, (int)((size_t)p.Cout * Ktot * 2), 0x00020000);
+    int a_iy0[MI], a_ix0[MI], a_base[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int gr = m0 + i * 32 + l31;
+        if (gr < p.rows) {
+            const int hw = p.Ho * p.Wo;
+            const int m = gr / hw;
+            const int rem = gr - m * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_base[i] = (int)(((long)m * p.H * p.W + (long)a_iy0[i] * p.W + a_ix0[i]) * p.xcs * 2 + lhi * 16);
+        } else {
+            a_iy0[i] = -100000; a_ix0[i] = 0; a_base[i] = 0;
+        }
+    }
+    const unsigned b_off = (unsigned)((size_t)(n0 + l31) * Ktot * 2 + lhi * 16);
+
+    const int t_begin = (z * p.ktiles) / n_split, t_end = ((z + 1) * p.ktiles) / n_split;
+    const int ntap = p.ks * p.ks;
+    const bool s2order = p.ks == 3 && p.stride == 2;
+    int st_ct = t_begin / ntap;
+    int st_tap = t_begin - st_ct * ntap;
+    int st_ky = st_tap / p.ks, st_kx = st_tap % p.ks;
+    if (s2order) s2_tap(st_tap, st_ky, st_kx);
+
+    struct Frags { u32x4_t a[4][MI], b[4]; };
+    auto load = [&](Frags& f, bool live) {                        // K-step (st_ct, st_tap): 16 bytes per lane per MFMA operand
+        const int tap_off = (st_ky * p.W + st_kx) * p.xcs * 2;
+        const int c_off = st_ct * 128;
+        const int w_off = (st_ky * p.ks + st_kx) * p.Cin * 2 + c_off;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int iy = a_iy0[i] + st_ky, ix = a_ix0[i] + st_kx;
+            const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned vo = ok ? (unsigned)(a_base[i] + tap_off) : 0x80000000u;     // out of range: the bounds check returns 0
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) f.a[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + kk * 32, c_off, 0);
+        }
+        const unsigned wo = live ? b_off : 0x80000000u;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) f.b[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo + kk * 32, w_off, 0);
+        if (++st_tap == ntap) { st_tap = 0; ++st_ct; }
+        if (s2order) s2_tap(st_tap, st_ky, st_kx);
+        else { st_ky = st_tap / p.ks; st_kx = st_tap - st_ky * p.ks; }
+    };
+    f32x16_t acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    auto compute = [&](const Frags& f) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.b[kk]),
+                                                                 __builtin_bit_cast(bf16x8_t, f.a[kk][i]), acc[i], 0, 0, 0);
+    };
+    const int KT = t_end - t_begin;
+    if constexpr (UF > 0) if (KT > UF) __builtin_trap();      // (the host picks UF >= the longest split)
+    if constexpr (UF > 0) {
+        // short range (the dispatched case: 3..5 K-steps per wave): EVERY load of the wave is issued before its first MFMA -- one
+        // memory latency per wave instead of one per K-step.  Slots past the range load nothing (offset out of range) and are skipped.
+        Frags f[UF > 0 ? UF : 1];
+#pragma unroll
+        for (int i = 0; i < UF; ++i) load(f[i], i < KT);
+#pragma unroll
+        for (int i = 0; i < UF; ++i)
+            if (i < KT) compute(f[i]);
+    } else {
+        Frags f0, f1;
+        int t = t_begin;
+        load(f0, true);
+        while (true) {
+            if (t + 1 < t_end) load(f1, true);
+            compute(f0);
+            if (++t >= t_end) break;
+            if (t + 1 < t_end) load(f0, true);
+            compute(f1);
+            if (++t >= t_end) break;
+        }
+    }
+    // partial tile of split z -> LDS, f32 [BM_][CLD] (D column = pixel, D rows 8 eg + 4 lhi .. + 4 = four consecutive channels)
+    float* const mine = part + (size_t)z * (BM_ * CLD);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg)
+            *reinterpret_cast<f32x4_t*>(mine + (i * 32 + l31) * CLD + eg * 8 + lhi * 4) =
+                f32x4_t{acc[i][eg * 4], acc[i][eg * 4 + 1], acc[i][eg * 4 + 2], acc[i][eg * 4 + 3]};
+    __syncthreads();
+    for (int id = tid; id < BM_ * CG; id += (int)blockDim.x) {      // (fewer than 4 splits: fewer threads than read-out items)
+        const int r = id / CG, cg = id - r * CG;
+        const int gr = m0 + r;
+        if (gr >= p.rows) continue;
+        const float* sp = part + r * CLD + cg * 8;
+        f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        for (int s = 0; s < n_split; ++s) {
+            v0 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)s * (BM_ * CLD));
+            v1 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)s * (BM_ * CLD) + 4);
+        }
+        splitk_epilogue8(p, v0, v1, g * p.Cout + n0 + cg * 8, (size_t)gr * p.ycs + (size_t)g * p.ygs + n0 + cg * 8);
+    }
+#endif
+}
+
+template <int BM_, int UF, int MAXT>
+int launch_conv_inwg_splitk(ConvArgs& a, int groups, int ksplit, hipStream_t s) {
+    a.cin_tiles = a.Cin / 64;
+    a.ktiles = a.ks * a.ks * a.cin_tiles;
+    a.ntm = (a.rows + BM_ - 1) / BM_;
+    a.ntn = a.Cout / 32;
+    a.n_split = ksplit;
+    const int lds = ksplit * BM_ * 36 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_inwg_splitk_kernel<BM_, UF, MAXT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_inwg_splitk_kernel<BM_, UF, MAXT>), dim3(a.ntm * a.ntn, groups), dim3(64 * ksplit), lds, s, a);
+    return w2c_launch_status();
 }
 
 // split-K launch of the generic kernel (grid.z = ksplit) + its finish kernel
@@ -1915,6 +2075,20 @@ extern "C" int w2c_conv_igemm_bf16_splitk(const uint16_t* x, int M, int H, int W
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const SplitPlan sp = plan_splitk(a, groups, ksplit);
     if (sp.ksplit <= 1) return launch_variant(pick_variant(a, groups), a, groups, s);
+    // up to 12 splits: the splits are the waves of one workgroup and the partial tiles meet in LDS (same bits, one launch, no workspace)
+    if (sp.ksplit <= 12 && a.Cin % 64 == 0 && a.Cout % 32 == 0 && w2c_option(W2C_OPT_INWG_SPLITK))
+    {
+        // 64-row tiles while the partial tiles fit the 80 KB budget (<= 8 splits), 32-row tiles above; a wave with <= 3 K-steps
+        // issues all of its loads up front.  (Measured, tools/bench_tail.py, us per conv inside a graph, two launches -> one:
+        // policy conv3 15.8 -> 14.5, conv4 16.2 -> 13.8, conv5 11.1 -> 10.1, decoder's last conv 15.1 -> 10.4.  32-row tiles with 5
+        // K-steps up front: 19.9 -- the bound is the bytes a CU can pull per second, ~47 GB/s per workgroup whatever the ring
+        // depth, so halving the tile doubles the weight traffic and loses.)
+        const int kt = a.ks * a.ks * (a.Cin / 64);
+        const int per_wave = (kt + sp.ksplit - 1) / sp.ksplit;           // K-steps of the longest split
+        if (sp.ksplit <= 8) return launch_conv_inwg_splitk<64, 0, 512>(a, groups, sp.ksplit, s);
+        return per_wave <= 3 ? launch_conv_inwg_splitk<32, 3, 768>(a, groups, sp.ksplit, s)
+                             : launch_conv_inwg_splitk<32, 0, 768>(a, groups, sp.ksplit, s);
+    }
     const long long need = (long long)sp.tiles * sp.ksplit * sp.bm * sp.bn * 4;
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return W2C_E_ARG;
     a.ws = reinterpret_cast<float*>(workspace);
@@ -1928,6 +2102,15 @@ static thread_local unsigned long long* g_dbg_next = nullptr;
 extern "C" int w2c_debug_conv_timeline(void* buf) {
     g_dbg_next = reinterpret_cast<unsigned long long*>(buf);
     return W2C_OK;
+}
+
+// Debug: one-thread kernel that writes the 100 MHz wall clock to slot[0] -- a time stamp in stream order (tools/chain_stamps.py:
+// when does each launch chain of a captured forward start?).
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+extern "C" int w2c_debug_stamp(void* slot, w2c_stream_t stream) {
+    w2c_clear_error();
+    stamp_kernel<<<1, 1, 0, reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<unsigned long long*>(slot));
+    return w2c_launch_status();
 }
 
 extern "C" int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,

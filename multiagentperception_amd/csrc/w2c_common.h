@@ -88,6 +88,7 @@ enum W2COption {
     W2C_OPT_STEM_BAND,        // 8 (default) | 4
     W2C_OPT_STEM_WAVES,       // 8 (default) | 12
     W2C_OPT_WGRAD_PATCH,      // 1 (default) | 0: halo-patch weight-gradient kernel
+    W2C_OPT_INWG_SPLITK,      // 1 (default) | 0: split-K convs with <= 12 splits as ONE launch (splits = waves, partials in LDS)
     W2C_OPT_COUNT
 };
 int w2c_option(int id);

@@ -144,6 +144,15 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
     return (t8 if f8 else t16), idt
 
 
+STAMPS = None          # debug (tools/chain_stamps.py): an int64 device tensor -> after_stem writes wall-clock stamps in stream order
+
+
+def _stamp(slot):
+    if STAMPS is not None:
+        from . import _native
+        _native.lib().w2c_debug_stamp(STAMPS.data_ptr() + 8 * slot, torch.cuda.current_stream(STAMPS.device).cuda_stream)
+
+
 class TrunkPlan:
     """G ResNet-18 trunks + squeezers run side by side (G = 1 for Single_agent, 2 for MIMOcom*).
 
@@ -243,17 +252,21 @@ class TrunkPlan:
         sq = None if squeezer_out is not None else torch.empty((M, Hs, Ws, self.G * feat), dtype=BF16, device=p.device)
         main = torch.cuda.current_stream(p.device)
         side = self._side_stream(p.device)
+        _stamp(0)
         side.wait_stream(main)
 
         def chain(g):
+            _stamp(1 + g)
             q, off = p, g * cin0
-            for c1, c2, ds in plans[g][0]:
+            for bi, (c1, c2, ds) in enumerate(plans[g][0]):
                 t, idt = _block_front(c1, ds, q, x_ch_off=off)       # the chain's first block is a stride-2 block: idt is its own
                 q, off = c2.run(t, residual=idt), 0
+                _stamp(8 + 8 * g + bi)
             if squeezer_out is not None:
                 plans[g][1].run(q, out_groups=[squeezer_out[g]])
             else:
                 plans[g][1].run(q, out=sq, out_ch_off=g * feat)
+            _stamp(3 + g)
 
         state = None
         with torch.cuda.stream(side):
@@ -262,6 +275,7 @@ class TrunkPlan:
                 state = policy_next[0](sq if squeezer_out is None else squeezer_out[1])
         chain(0)
         main.wait_stream(side)
+        _stamp(5)
         extra = policy_next[1](state) if policy_next is not None else None
         res = list(squeezer_out) if squeezer_out is not None else sq
         return (res, extra) if policy_next is not None else res
@@ -364,11 +378,13 @@ class TrunkPlan:
             self._rest_bf16(p, sq if squeezer_out is None else None, squeezer_out, feat)
         return list(squeezer_out) if squeezer_out is not None else sq
 
-    def _side_stream(self, dev):
+    def _side_stream(self, dev, idx=0):
         st = self.__dict__.setdefault("_side", {})
-        if dev not in st:
-            st[dev] = torch.cuda.Stream(device=dev)      # (a high-priority side stream measured 2.3 ms per forward instead of 1.25)
-        return st[dev]
+        if (dev, idx) not in st:
+            # (default priority: a high-priority side stream does not favour its chain -- both chains advance in lock-step, each
+            # block ~25 % slower: 1.45 ms per forward under graph replay, profiles/r03_concurrency.txt)
+            st[(dev, idx)] = torch.cuda.Stream(device=dev)
+        return st[(dev, idx)]
 
     def _rest_bf16(self, p, sq, squeezer_out, feat):
         """the trunks that stay bf16 (the policy encoder): same blocks, one group each launch, reading their slice of

@@ -64,6 +64,23 @@ class KernelTimer:
             e[2] += 1
         return total_ms, total_fl, len(self.records), per
 
+    def busy_ms(self):
+        """Length of the UNION of the recorded launches' [start, end] intervals (ms; call after a sync).  The two trunks run as two
+        concurrent launch chains on two streams (engine.TrunkPlan.after_stem): launches that share the chip each take longer than
+        alone, and the sum of their durations counts that wall time twice.  The union is the time the chip spent in the family."""
+        if not self.records:
+            return 0.0
+        base = self.records[0][0]
+        spans = sorted((base.elapsed_time(st), base.elapsed_time(en)) for st, en, _, _, _ in self.records)
+        busy, lo, hi = 0.0, spans[0][0], spans[0][1]
+        for a, b in spans[1:]:
+            if a > hi:
+                busy += hi - lo
+                lo, hi = a, b
+            else:
+                hi = max(hi, b)
+        return busy + (hi - lo)
+
 
 _tls = threading.local()          # per-thread (DataParallel runs one thread per replica): the opt-in conv timer
 

@@ -181,13 +181,17 @@ SPLITK_CASES = [
     (3, 3, 9, 7, 128, 64, 3, 1, 2, True, False),           # forced 3-way, ragged rows, both groups, residual
     (18, 1, 8, 8, 128, 64, 3, 1, 1, True, True),           # one K-step per workgroup
     (4, 2, 8, 8, 256, 128, 1, 1, 1, False, False),         # 1x1
+    (0, 20, 8, 8, 256, 256, 3, 1, 1, False, False),        # policy conv3 / conv4: 8 splits = 8 waves of one workgroup
+    (12, 3, 5, 7, 256, 96, 3, 1, 2, True, False),          # 12 splits (32-row tiles), ragged rows, two groups, residual
+    (7, 5, 6, 6, 128, 64, 3, 2, 1, False, True),           # 7 splits of 18 K-steps (uneven ranges), stride 2, f32 out
 ]
 
 
 @pytest.mark.parametrize("case", SPLITK_CASES, ids=["k%d-%d" % (c[0], i) for i, c in enumerate(SPLITK_CASES)])
-def test_conv_splitk_matches_fp32_and_is_deterministic(case):
-    """Split-K tail-layer path: fp32 parity, bit-identical across repeated launches (fixed summation order, arrival
-    counters restored), and equal to the one-workgroup-per-tile kernel up to f32 summation order."""
+def test_conv_splitk_matches_fp32_and_is_deterministic(case, lib_option):
+    """Split-K tail-layer path: fp32 parity, bit-identical across repeated launches (fixed summation order), equal to the
+    one-workgroup-per-tile kernel up to f32 summation order, and the one-launch form (splits = waves of one workgroup, partial tiles
+    in LDS: conv_inwg_splitk_kernel, taken for <= 12 splits) bit-identical to the two-launch form (workspace + finish kernel)."""
     from multiagentperception_amd import ops
     ksplit, M, H, W, cin, cout, ks, stride, G, use_res, f32out = case
     gen = torch.Generator().manual_seed(7000 + ksplit + cout)
@@ -212,6 +216,10 @@ def test_conv_splitk_matches_fp32_and_is_deterministic(case):
     plain = ops.conv_igemm(*args, **kw)
     torch.cuda.synchronize()
     assert float((first.float() - plain.float()).abs().max()) <= (1e-4 if f32out else 0.0626)
+    lib_option("W2C_INWG_SPLITK", 0)
+    two_launch = ops.conv_igemm(*args, ksplit=ksplit, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(two_launch, first)
     for g in range(G):
         ref = F.conv2d(xs[g], ws[g], None, stride=stride, padding=pad)
         ref = ref * scale[g * cout:(g + 1) * cout].view(1, -1, 1, 1) + shift[g * cout:(g + 1) * cout].view(1, -1, 1, 1)

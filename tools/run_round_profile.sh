@@ -1,12 +1,12 @@
+# round profile: the bench line (with PMC traffic + CPU baseline), rocprofv3 --kernel-trace --stats of the same command, digest
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02d
-python -m pytest tests -m gpu -q -x > gpurun_out/r02d/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02d/pytest.log
-python bench.py > gpurun_out/r02d/bench.json 2> gpurun_out/r02d/bench.err
-python bench.py --config cfg5 --no-cpu-baseline > gpurun_out/r02d/bench_cfg5.json 2> gpurun_out/r02d/bench_cfg5.err
+OUT=gpurun_out/${1:-r03a}
+mkdir -p $OUT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof -o t -- python $R/bench.py --no-cpu-baseline --no-pmc > $R/gpurun_out/r02d/prof_bench.json 2> $R/gpurun_out/r02d/prof.err
+cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof -o t -- python $R/bench.py --no-cpu-baseline --no-pmc > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err
 DB=$(find /tmp/prof -name '*.db' | head -1)
-python $R/tools/rocprof_summary.py $DB --forward > $R/gpurun_out/r02d/kernel_trace_stats.txt 2>&1
-tail -3 $R/gpurun_out/r02d/pytest.log
-cat $R/gpurun_out/r02d/bench.json $R/gpurun_out/r02d/bench_cfg5.json
+python $R/tools/rocprof_summary.py $DB --forward > $R/$OUT/kernel_trace_stats.txt 2>&1
+cat $R/$OUT/bench.json
+head -60 $R/$OUT/kernel_trace_stats.txt
