@@ -241,6 +241,10 @@ int w2c_debug_fp8_pack(const float* x, uint8_t* y, int n, w2c_stream_t stream);
  * 4 x uint64 wall-clock stamps per workgroup (start, first tile landed, main loop done, end; 100 MHz) into buf
  * (device memory, >= 32 bytes x workgroups). */
 int w2c_debug_conv_timeline(void* buf);
+/* Measurement: the next conv entry call of this thread (w2c_conv_igemm_bf16[_splitk|_variant], w2c_conv_igemm_fp8, w2c_conv_s2_block)
+   records its launch span into slot[0] = min start stamp, slot[1] = max end stamp over its workgroups (u64, 100 MHz wall clock;
+   preset {~0, 0}).  The pointer travels as a kernel argument: a launch captured into a HIP graph records on every replay. */
+int w2c_debug_conv_span(void* slot);
 /* Debug: enqueue a one-thread kernel that writes the 100 MHz wall clock to *slot (u64): a time stamp in stream order. */
 int w2c_debug_stamp(void* slot, w2c_stream_t stream);
 

@@ -60,6 +60,16 @@ extern "C" int w2c_get_option(const char* name) {
     return -1;
 }
 
+// Debug / measurement: the next conv entry call of THIS thread makes its kernels record the launch's span -- min over workgroups of the
+// start stamp, max of the end stamp (100 MHz wall clock) -- into slot[0..1] (u64; the caller presets {~0, 0}).  The pointer is a kernel
+// argument, so a launch captured into a HIP graph keeps recording on every replay: bench.py times the conv family under graph
+// replay, where the two trunk chains overlap, without a profiler.  Costs two atomics per workgroup when set, one scalar branch when not.
+static thread_local unsigned long long* g_span_next = nullptr;
+extern "C" int w2c_debug_conv_span(void* slot) {
+    g_span_next = reinterpret_cast<unsigned long long*>(slot);
+    return W2C_OK;
+}
+
 namespace {
 
 struct ConvArgs {
@@ -79,6 +89,8 @@ struct ConvArgs {
     int ktiles;      // ks*ks*cin_tiles
     int ntm, ntn;    // tiles along rows / cout
     unsigned long long* dbg;   // optional timeline buffer (tools/conv_timeline.py): 4 x u64 per workgroup, else null
+    unsigned long long* span;  // optional launch span (bench.py's roofline pass): [0] = min over workgroups of the start stamp,
+                               // [1] = max of the end stamp (100 MHz wall clock), else null
     float* ws;                 // split-K: f32 partial tiles [group][tile][split][BM][BN]
     int n_split;
     long long ygs;             // element offset between the groups' output (and residual) slabs; Cout = side by side
@@ -120,9 +132,17 @@ __device__ __forceinline__ void store_out8(const ConvArgs& p, const float (&v)[8
 }
 
 
+__device__ __forceinline__ void span_stamp(const ConvArgs& p, bool end) {
+    if (p.span && threadIdx.x == 0) {
+        if (end) atomicMax(p.span + 1, (unsigned long long)wall_clock64());
+        else atomicMin(p.span, (unsigned long long)wall_clock64());
+    }
+}
 __device__ __forceinline__ void dbg_stamp(const ConvArgs& p, int slot) {
     if (p.dbg && threadIdx.x == 0)
         p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + slot] = wall_clock64();
+    if (slot == 0) span_stamp(p, false);
+    if (slot == 3) span_stamp(p, true);
 }
 
 // Tap order of the stride-2 3x3 convs: grouped by input phase (see conv3x3s2_patch_kernel) -- every kernel that computes a
@@ -1262,6 +1282,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
     // A fragment is 16 B out of a 1152-B weight row: gathering it straight from global memory costs 72 uncoalesced
     // loads per lane, so the group's 73 KB go through LDS once (coalesced in, fragment-shaped out). ----
     const unsigned long long wall0 = p.dbg ? wall_clock64() : 0;
+    span_stamp(p, false);
     u32x4_t wa[9][4], wv[9][4];
     {
         const uint16_t* wg = p.w + (size_t)g * 64 * 576;
@@ -1522,6 +1543,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
         for (int i = 0; i < 4; ++i) d[i] = ph[i];
         d[4] = wall0; d[5] = wall1; d[6] = wall_clock64(); d[7] = 1;
     }
+    span_stamp(p, true);
 #endif
 }
 
@@ -1631,6 +1653,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
     const int g = blockIdx.y;
     const long total = (long)p.ntm * p.ntn * BM * CG;
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    span_stamp(p, true);                                     // (a launch span ends with its finish kernel; thread 0 may leave early)
     if (id >= total) return;
     const int cg = (int)(id % CG);
     const long t1 = id / CG;
@@ -1646,6 +1669,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
         v1 += *reinterpret_cast<const f32x4_t*>(sp + (size_t)z * (BM * BN) + 4);
     }
     splitk_epilogue8(p, v0, v1, g * p.Cout + tn * BN + cg * 8, (size_t)gr * p.ycs + (size_t)g * p.ygs + tn * BN + cg * 8);
+    span_stamp(p, true);
 }
 
 // Split-K INSIDE one workgroup, for the tail layers (policy conv2..5, the decoder's last 3x3: <= 1280 output rows under a
@@ -1663,6 +1687,7 @@ __global__ __launch_bounds__(MAXT) void conv_inwg_splitk_kernel(ConvArgs p) {
     constexpr int BN_ = 32, MI = BM_ / 32, CLD = BN_ + 4, CG = BN_ / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const part = reinterpret_cast<float*>(smem);          // [split][BM_][CLD]
+    span_stamp(p, false);
     const int tid = threadIdx.x, lane = tid & 63;
     const int z = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_split = p.n_split;
@@ -1783,6 +1808,7 @@ __global__ __launch_bounds__(MAXT) void conv_inwg_splitk_kernel(ConvArgs p) {
         }
         splitk_epilogue8(p, v0, v1, g * p.Cout + n0 + cg * 8, (size_t)gr * p.ycs + (size_t)g * p.ygs + n0 + cg * 8);
     }
+    span_stamp(p, true);
 #endif
 }
 
@@ -2020,6 +2046,8 @@ int fill_args(ConvArgs& a, const void* x, int M, int H, int W, int Cin, int x_cs
         return W2C_E_ARG;
     a.rows = M * a.Ho * a.Wo;
     a.dbg = nullptr;
+    a.span = g_span_next;            // (w2c_debug_conv_span: the next conv call of this thread records its launch span)
+    g_span_next = nullptr;
     a.ws = nullptr;
     a.n_split = 1;
     a.ygs = y_group_stride;

@@ -44,34 +44,76 @@ class KernelTimer:
     the launch stream (torch.cuda.Event on torch's current stream == the stream we launch on).
     Used by bench.py's roofline attribution pass only; never active inside its timed region."""
 
-    def __init__(self):
-        self.records = []          # (start_event, end_event, flops, key, algorithmic bytes)
+    def __init__(self, spans=False, device=None, capacity=4096):
+        self.records = []          # (start_event | span slot, end_event | None, flops, key, algorithmic bytes)
+        self.spans = bool(spans)
+        if self.spans:
+            # span mode (bench.py under HIP-graph replay): every conv launch carries a pointer to its own slot of this buffer and its
+            # workgroups record min(start) / max(end) of the 100 MHz wall clock there -- on every replay of the captured graph
+            # (include/w2c_hip.h w2c_debug_conv_span).  reset() before a replay, read after a sync.
+            self.buf = torch.empty((capacity, 2), dtype=torch.int64, device=device)
+            self.reset()
+
+    def reset(self):
+        self.buf[:, 0] = torch.iinfo(torch.int64).max       # (stamps are far below 2^63: signed and unsigned order agree)
+        self.buf[:, 1] = 0
+
+    def begin(self, dev):
+        if self.spans:
+            idx = len(self.records)
+            if idx >= self.buf.shape[0]:
+                raise W2CError("KernelTimer: span buffer full")
+            check(_native.lib().w2c_debug_conv_span(self.buf.data_ptr() + 16 * idx), "w2c_debug_conv_span")
+            return idx
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        return ev0
+
+    def end(self, token, dev, flops, key, nbytes):
+        if self.spans:
+            self.records.append((token, None, flops, key, nbytes))
+            return
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream(dev))
+        self.records.append((token, ev1, flops, key, nbytes))
+
+    def _intervals(self):
+        """[(start_ms, end_ms, record)] of the launches that ran since the last reset (span mode) / of all records (event mode)"""
+        if self.spans:
+            t = self.buf[:len(self.records)].cpu().numpy()
+            live = [(int(t[i, 0]), int(t[i, 1]), r) for i, r in enumerate(self.records) if t[i, 1] > 0]
+            if not live:
+                return []
+            t0 = min(a for a, _, _ in live)
+            return [((a - t0) * 1e-5, (b - t0) * 1e-5, r) for a, b, r in live]           # 100 MHz ticks -> ms
+        base = self.records[0][0]
+        return [(base.elapsed_time(r[0]), base.elapsed_time(r[1]), r) for r in self.records]
 
     def algorithmic_bytes(self):
-        """sum over the recorded launches of input + output (+ residual) activations + weights, each once."""
-        return float(sum(r[4] for r in self.records))
+        """sum over the measured launches of input + output (+ residual) activations + weights, each once."""
+        return float(sum(r[4] for _, _, r in self._intervals()))
 
     def summary(self):
         """-> total_ms, total_flops, launches, per-shape {key: [ms, flops, count]} (call after a sync)."""
-        total_ms, total_fl, per = 0.0, 0.0, {}
-        for st, en, fl, key, _ in self.records:
-            ms = st.elapsed_time(en)
+        total_ms, total_fl, per, n = 0.0, 0.0, {}, 0
+        for a, b, r in self._intervals():
+            ms, fl, key = b - a, r[2], r[3]
             total_ms += ms
             total_fl += fl
+            n += 1
             e = per.setdefault(key, [0.0, 0.0, 0])
             e[0] += ms
             e[1] += fl
             e[2] += 1
-        return total_ms, total_fl, len(self.records), per
+        return total_ms, total_fl, n, per
 
     def busy_ms(self):
-        """Length of the UNION of the recorded launches' [start, end] intervals (ms; call after a sync).  The two trunks run as two
+        """Length of the UNION of the measured launches' [start, end] intervals (ms; call after a sync).  The two trunks run as two
         concurrent launch chains on two streams (engine.TrunkPlan.after_stem): launches that share the chip each take longer than
         alone, and the sum of their durations counts that wall time twice.  The union is the time the chip spent in the family."""
-        if not self.records:
+        spans = sorted((a, b) for a, b, _ in self._intervals())
+        if not spans:
             return 0.0
-        base = self.records[0][0]
-        spans = sorted((base.elapsed_time(st), base.elapsed_time(en)) for st, en, _, _, _ in self.records)
         busy, lo, hi = 0.0, spans[0][0], spans[0][1]
         for a, b in spans[1:]:
             if a > hi:
@@ -251,10 +293,7 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     xptr = x.data_ptr() + 2 * x_ch_off
     optr = out.data_ptr() + (4 if out_f32 else 2) * out_ch_off
     timer = getattr(_tls, "conv_timer", None)
-    if timer is not None:
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record(torch.cuda.current_stream(dev))
+    tok = timer.begin(dev) if timer is not None else None
     with torch.cuda.device(dev):
         ws_bytes = 0
         if ksplit is not None and variant is None:
@@ -281,11 +320,10 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
                                                             1 if out_f32 else 0, _p(zero_page(dev)), int(variant),
                                                             int(_gstride), _stream(dev)), "w2c_conv_igemm_bf16_variant(%d)" % variant)
     if timer is not None:
-        ev1.record(torch.cuda.current_stream(dev))
         flops = 2.0 * M * Ho * Wo * cout * (ksize * ksize * cin) * groups
         nbytes = (M * H * W * cin * groups * 2 + M * Ho * Wo * cout * groups * (4 if out_f32 else 2)
                   + (M * Ho * Wo * cout * groups * 2 if residual is not None else 0) + groups * cout * ksize * ksize * cin * 2)
-        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups), nbytes))
+        timer.end(tok, dev, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups), nbytes)
     return out
 
 
@@ -340,10 +378,7 @@ def conv_fp8(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shi
                                  or out_groups is not None):
         raise W2CError("conv_fp8: residual must be bf16 [M,Ho,Wo,groups*cout] (and excludes out_groups)")
     timer = getattr(_tls, "conv_timer", None)
-    if timer is not None:
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record(torch.cuda.current_stream(dev))
+    tok = timer.begin(dev) if timer is not None else None
     es = 1 if f8 else 2
     with torch.cuda.device(dev):
         check(_native.lib().w2c_conv_igemm_fp8(x.data_ptr() + es * x_ch_off, 1 if f8 else 0, M, H, W, cin, xcs, _p(w_packed),
@@ -353,11 +388,10 @@ def conv_fp8(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, shi
                                                float(out_fp8_scale) if out_fp8_scale is not None else 1.0,
                                                _p(zero_page(dev)), int(variant), _stream(dev)), "w2c_conv_igemm_fp8")
     if timer is not None:
-        ev1.record(torch.cuda.current_stream(dev))
         flops = 2.0 * M * Ho * Wo * cout * (ksize * ksize * cin) * groups
         nbytes = (M * H * W * cin * groups * es + M * Ho * Wo * cout * groups * ((2 if y is not None else 0) + (1 if y8 is not None else 0))
                   + (M * Ho * Wo * cout * groups * 2 if residual is not None else 0) + groups * cout * ksize * ksize * cin * es)
-        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups, "fp8" if f8 else "bf16>fp8"), nbytes))
+        timer.end(tok, dev, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups, "fp8" if f8 else "bf16>fp8"), nbytes)
     return (list(out_groups) if out_groups is not None else y), y8
 
 
@@ -381,10 +415,7 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
     idt = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
     es = 1 if f8 else 2
     timer = getattr(_tls, "conv_timer", None)
-    if timer is not None:
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record(torch.cuda.current_stream(dev))
+    tok = timer.begin(dev) if timer is not None else None
     with torch.cuda.device(dev):
         check(_native.lib().w2c_conv_s2_block(x.data_ptr() + es * x_ch_off, 1 if f8 else 0, M, H, W, cin, xcs, _p(w3), _p(scale3),
                                               _p(shift3), _p(w1), _p(scale1), _p(shift1), cout, groups, _p(t16), groups * cout,
@@ -392,11 +423,10 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
                                               _p(idt), groups * cout, _p(zero_page(dev)), int(variant), _stream(dev)),
               "w2c_conv_s2_block")
     if timer is not None:
-        ev1.record(torch.cuda.current_stream(dev))
         flops = 2.0 * M * Ho * Wo * cout * (10 * cin) * groups
         nbytes = (M * H * W * cin * groups * es + M * Ho * Wo * cout * groups * ((2 if t16 is not None else 0) + (1 if t8 is not None else 0) + 2)
                   + groups * cout * 10 * cin * es)
-        timer.records.append((ev0, ev1, flops, (M * Ho * Wo, cin, cout, "3+1", 2, groups), nbytes))
+        timer.end(tok, dev, flops, (M * Ho * Wo, cin, cout, "3+1", 2, groups), nbytes)
     return t16, t8, idt
 
 
@@ -415,19 +445,17 @@ def conv_block_c64(x, w1, scale1, shift1, w2, scale2, shift2, groups, out=None, 
     if out.dtype != BF16 or out.shape[:3] != x.shape[:3] or out.shape[3] < groups * 64 or out.data_ptr() == x.data_ptr():
         raise W2CError("conv_block_c64: out must be a different bf16 NHWC tensor of the same spatial shape")
     timer = getattr(_tls, "conv_timer", None)
-    if timer is not None:
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record(torch.cuda.current_stream(dev))
+    if timer is not None and timer.spans:
+        timer = None                               # (csrc/conv_block.hip takes no span pointer)
+    tok = timer.begin(dev) if timer is not None else None
     with torch.cuda.device(dev):
         check(_native.lib().w2c_conv_block_c64(_p(x), M, H, W, xcs, _p(w1), _p(scale1), _p(shift1), _p(w2), _p(scale2), _p(shift2),
                                                groups, _p(out), out.shape[3], int(max_workgroups), _stream(dev)),
               "w2c_conv_block_c64")
     if timer is not None:
-        ev1.record(torch.cuda.current_stream(dev))
         flops = 2.0 * 2.0 * M * H * W * 64 * 576 * groups
         nbytes = 2 * M * H * W * 64 * groups * 2 + 2 * groups * 64 * 576 * 2
-        timer.records.append((ev0, ev1, flops, (M * H * W, 64, 64, "3,3 block", 1, groups), nbytes))
+        timer.end(tok, dev, flops, (M * H * W, 64, 64, "3,3 block", 1, groups), nbytes)
     return out
 
 

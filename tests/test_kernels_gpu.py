@@ -873,3 +873,53 @@ def test_comm_graph_fuse_equals_the_two_launches(who, mode, B, N, has_q, q_lo, q
     assert torch.equal(prob2, prob) and torch.equal(coef2, coef) and torch.equal(action2, action) and torch.equal(nnz2, nnz)
     p3, a3, n3 = ops.carve_graph_outputs(pack.clone(), B, N, q_n)
     assert torch.equal(p3, prob) and torch.equal(a3, action) and torch.equal(n3, nnz)
+
+
+def test_conv_launch_spans_are_recorded_on_every_graph_replay():
+    """bench.py's roofline pass (ops.KernelTimer(spans=True)): a conv launch given a span slot (w2c_debug_conv_span) records the
+    min start / max end wall-clock stamp of its workgroups -- as a kernel argument, so a launch captured into a HIP graph keeps
+    recording on every replay.  Two dependent launches (a patch-kernel conv, then a split-K tail conv): spans ordered, non-empty,
+    refreshed per replay, results untouched."""
+    from multiagentperception_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(5)
+    x = _rand(gen, 4, 16, 16, 256).to(BF16).to(dev)
+    w1 = (_rand(gen, 1, 256, 9 * 256) * 0.02).to(BF16).to(dev)
+    w2 = (_rand(gen, 1, 256, 9 * 256) * 0.02).to(BF16).to(dev)
+    sc, sh = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+
+    def two_convs():
+        t = ops.conv_igemm(x, 0, 256, w1, 256, 3, 1, 1, sc, sh)
+        return ops.conv_igemm(t, 0, 256, w2, 256, 3, 2, 1, sc, sh, ksplit=0)
+
+    plain = two_convs().clone()
+    timer = ops.KernelTimer(spans=True, device=dev)
+    ops.set_conv_timer(timer)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            two_convs()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        n_eager = len(timer.records)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = two_convs()
+    finally:
+        ops.set_conv_timer(None)
+    assert n_eager == 2 and len(timer.records) == 4
+    seen = []
+    for _ in range(2):
+        timer.reset()
+        g.replay()
+        torch.cuda.synchronize()
+        spans = timer._intervals()
+        assert len(spans) == 2                                   # only the captured launches ran since the reset
+        (a0, b0, r0), (a1, b1, r1) = spans
+        assert 0.0 <= a0 < b0 <= a1 < b1 and b1 < 5.0            # ms; the second launch depends on the first
+        assert r0[3][:3] == (4 * 16 * 16, 256, 256) and r1[3][:3] == (4 * 8 * 8, 256, 256)
+        assert abs(timer.busy_ms() - ((b0 - a0) + (b1 - a1))) < 1e-9
+        seen.append(int(timer.buf[2, 0]))
+        assert torch.equal(y, plain)
+    assert seen[1] > seen[0]                                     # a fresh stamp per replay
