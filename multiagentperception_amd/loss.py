@@ -20,6 +20,31 @@ from . import ops
 logger = logging.getLogger("ptsemseg")
 IGNORE_INDEX = 250          # loss.py:16
 
+# Labels outside [0, C) that are not 250: F.cross_entropy device-asserts on them (the reference's behaviour); the kernel drops them
+# from numerator, denominator and gradient and COUNTS them (out3[2]).  The count is accumulated on the device without a sync and read
+# on the first call, then every _LABEL_CHECK_EVERY calls (every call with W2C_CHECK_LABELS=1): a mislabelled dataset raises instead
+# of training on silently.
+_LABEL_CHECK_EVERY = 256
+_bad_labels = {}            # device -> [accumulated count tensor, calls since the last read, calls]
+
+
+def _note_bad_labels(out3):
+    import os
+    dev = out3.device
+    st = _bad_labels.get(dev)
+    if st is None:
+        st = _bad_labels[dev] = [torch.zeros((), dtype=torch.float64, device=dev), 0, 0]
+    st[0] += out3[2].double()
+    st[1] += 1
+    st[2] += 1
+    if st[2] == 1 or st[1] >= _LABEL_CHECK_EVERY or os.environ.get("W2C_CHECK_LABELS") == "1":
+        st[1] = 0
+        bad = int(st[0].item())
+        if bad:
+            st[0].zero_()
+            raise ValueError("cross_entropy2d: %d target values are outside [0, n_classes) and are not the ignore index %d "
+                             "(torch's cross_entropy asserts on these; this kernel drops them): check the label map" % (bad, IGNORE_INDEX))
+
 
 class _CrossEntropy2dFn(torch.autograd.Function):
     """mean (or sum) of w_t * nll over the kept pixels.  Inputs: logits NCHW f32 contiguous, target int64 [N,H,W]."""
@@ -27,6 +52,7 @@ class _CrossEntropy2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, weight, size_average):
         out3, lse, _ = ops.cross_entropy2d_forward(logits, target, weight, size_average, IGNORE_INDEX)
+        _note_bad_labels(out3)
         ctx.save_for_backward(logits, target, lse, out3)
         ctx.weight, ctx.size_average = weight, size_average
         return out3[0].clone()

@@ -4,10 +4,11 @@ the HIP engine.
 
 Dispatch rule (documented in DESIGN.md): ``module.eval()`` -> the HIP path, always -- it raises
 if the input is not on an MI355X or libw2c_hip.so is missing; there is no CPU/PyTorch fallback
-for it.  ``module.train()`` -> the reference's layer graph under autograd with the 3x3 / 1x1
-convolutions (forward, dX, dW) and the decoder upsample on the HIP kernels (train_ops.py;
-SURVEY.md section 8f row 3, stage 1); batch-statistics BatchNorm, ReLU, pooling, heads and
-attention are stock PyTorch-ROCm ops in the same graph.  Note the reference's ``training`` *argument* is only a return-shape
+for it.  ``module.train()`` -> the reference's layer graph under autograd with every convolution (forward, dX, dW; the 7x7
+stem included), train-mode BatchNorm + residual add + ReLU (train_ops.bn_act: w2c_bn_train_*, which also own the running-stat
+and num_batches_tracked updates), the resnet maxpool (w2c_maxpool3x3s2_train_*) and the decoder upsample + its adjoint on the
+HIP kernels (train_ops.py); the heads' linear layers, attention and fusion are stock PyTorch-ROCm ops
+in the same graph.  Note the reference's ``training`` *argument* is only a return-shape
 flag (validation calls training=True under eval(), trainer.py:692,713); it never selects the path.
 """
 import os
@@ -69,7 +70,11 @@ class _EngineCacheMixin:
     def set_trunk_precision(self, precision):
         """'bf16' (default), 'fp8' (value encoder's layer2..4 + squeezer convs on fp8 e4m3 MFMA; the policy encoder that
         drives the communication graph stays bf16) or 'fp8-all' (both encoders; for measurement) -- BASELINE.json
-        configs[4], see engine.TrunkPlan.  Not part of the reference API.  Drops the packed weights."""
+        configs[4], see engine.TrunkPlan.  Not part of the reference API.  Drops the packed weights.
+        fp8 is an opt-in mode OUTSIDE the path's accuracy bar (e4m3 operands cost 3e-2 of the logits per layer
+        group).  Its per-tensor activation scales are frozen from the FIRST batch the engine sees after this call (amax -> 256 of
+        e4m3's 448, i.e. 1.75x headroom; larger activations later saturate silently): make that first forward a representative
+        batch, not a warm-up tensor, and call this method again to recalibrate."""
         if precision not in ("bf16", "fp8", "fp8-all"):
             raise ValueError("trunk precision must be 'bf16', 'fp8' or 'fp8-all'")
         self.trunk_precision = precision
@@ -224,9 +229,10 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
         num_connect = self.agent_num - 1 if inference == "softmax" else int(nnz.sum().item()) / (self.agent_num * B)
         return labels, prob, action, num_connect
 
-    # ---- train-mode path: the reference's layer graph under autograd; the 3x3 / 1x1 convolutions
-    # (97 % of the FLOPs) run on the HIP kernels forward AND backward (train_ops.Conv2dHip), train-mode BatchNorm over
-    # the agent-concatenated batch (agent.py:1108-1111), ReLU, pooling, heads and attention on stock PyTorch-ROCm ops ------
+    # ---- train-mode path: the reference's layer graph under autograd.  Every convolution runs on the HIP
+    # kernels forward AND backward (train_ops.Conv2dHip), train-mode BatchNorm over the agent-concatenated batch
+    # (agent.py:1108-1111) + add + ReLU and the maxpool on the fused HIP kernels (models/blocks.py -> train_ops.bn_act /
+    # maxpool3x3s2); "stock ops" in the name refers to what is left: heads' linears, attention, fusion ------
     def _forward_train_stock_ops(self, inputs, training, MO_flag, inference):
         if not training:
             raise W2CError("module is in train() mode but forward(training=False) was requested; call .eval() "

@@ -526,7 +526,7 @@ def pack_conv_weights_both(weight):
     return fwd, dg
 
 
-def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups, oihw=False):
+def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups, oihw=False, _limit=None):
     """dW f32 [G, cout, ksize*ksize*cin] of the conv that maps x (bf16 NHWC, channels [x_ch_off, +G*cin)) to an output whose
     gradient is dy (bf16 NHWC [M,Ho,Wo,G*cout]).  include/w2c_hip.h w2c_conv_wgrad_bf16."""
     dev = _need_gpu(x, dy)
@@ -537,6 +537,19 @@ def conv_wgrad(x, x_ch_off, cin, dy, cout, ksize, stride, groups, oihw=False):
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     if tuple(dy.shape[:3]) != (M, Ho, Wo) or dy.shape[3] < groups * cout or x_ch_off < 0 or x_ch_off + groups * cin > xcs:
         raise W2CError("conv_wgrad: geometry mismatch")
+    # the kernel addresses x and dy through 31-bit buffer descriptors (like the forward, whose wrapper slices the batch): cut the
+    # batch into slices that fit and add the slices' dW in slice order (fixed order: deterministic)
+    lim = int(_limit) if _limit else (1 << 31) - 1
+    per_img = max(H * W * xcs * 2, Ho * Wo * dy.shape[3] * 2)
+    if M * per_img > lim:
+        step = max(1, lim // per_img)
+        if step >= M or per_img > lim:
+            raise W2CError("conv_wgrad: one image exceeds the kernels' 2 GiB addressing range")
+        total = None
+        for lo in range(0, M, step):
+            part = conv_wgrad(x[lo:lo + step], x_ch_off, cin, dy[lo:lo + step], cout, ksize, stride, groups, oihw=oihw, _limit=_limit)
+            total = part if total is None else total.add_(part)
+        return total
     need = _native.lib().w2c_conv_wgrad_workspace_bytes(M, H, W, cin, cout, ksize, stride, groups)
     if need < 0:
         raise W2CError("conv_wgrad: unsupported shape (Cin, Cout multiples of 64; 3x3 or 1x1; stride 1 or 2)")

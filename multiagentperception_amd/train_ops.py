@@ -168,8 +168,11 @@ def hip_supported_padded(conv):
 
 
 class Conv2dHip(nn.Conv2d):
-    """nn.Conv2d (same parameters, same state_dict keys) whose TRAIN-mode forward runs on the HIP conv kernels when the
-    backend is "hip", the input is on the GPU and the shape is one the kernels cover; see the module docstring."""
+    """nn.Conv2d (same parameters, same state_dict keys) whose forward -- whenever it is CALLED, i.e. on the autograd layer graph
+    the models run under module.train(); module.eval() never reaches these modules, it runs the packed engine -- goes to the HIP
+    conv kernels when the backend is "hip", the input is on the GPU and the shape is one the kernels cover; see the module
+    docstring.  (forward() does not look at self.training: a caller that drives the layer graph by hand in eval mode gets the
+    same kernels.)"""
 
     def forward(self, x):
         if _backend == "hip" and x.is_cuda and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:

@@ -57,6 +57,20 @@ def test_cross_entropy2d_is_deterministic_and_counts_bad_targets():
     assert float(c[0][1]) == float(keep.sum())
 
 
+def test_out_of_range_labels_raise_through_the_loss_function(monkeypatch):
+    """F.cross_entropy device-asserts on a label outside [0, C) that is not 250 (the reference); the kernel drops and counts them and
+    the loss function surfaces the count: on the first call of a process, periodically after that, every call with W2C_CHECK_LABELS=1."""
+    from multiagentperception_amd import loss as L
+    monkeypatch.setenv("W2C_CHECK_LABELS", "1")
+    logits, target = _case(2, 11, 32, 32, seed=3)
+    L.cross_entropy2d(logits, target)                      # clean labels: fine
+    target[1, 4, 4] = 255
+    with pytest.raises(ValueError, match="outside"):
+        L.cross_entropy2d(logits, target)
+    target[1, 4, 4] = 3
+    L.cross_entropy2d(logits, target)                      # the counter was cleared by the raise
+
+
 def test_all_pixels_ignored_gives_nan_mean_like_torch():
     from multiagentperception_amd.loss import cross_entropy2d
     logits, target = _case(1, 11, 8, 8, seed=1)

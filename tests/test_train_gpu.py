@@ -53,6 +53,28 @@ def test_conv_wgrad_matches_autograd(case):
         assert oihw.shape == (cout, cin, ks, ks) and torch.equal(oihw.cpu(), got[0].contiguous())
 
 
+def test_conv_wgrad_slices_a_batch_past_the_addressing_range():
+    """x / dy at or above 2 GiB (the kernels' 31-bit buffer descriptors): ops.conv_wgrad cuts the batch like ops.conv_igemm does and
+    adds the slices' dW in slice order -- here with the limit lowered so that 7 images become slices of 3 + 3 + 1."""
+    from multiagentperception_amd import ops
+    M, H, W, cin, cout = 7, 16, 16, 64, 128
+    gen = torch.Generator().manual_seed(11)
+    xd = torch.randn(M, H, W, cin, generator=gen).to(BF16).to(_dev())
+    dyd = torch.randn(M, H, W, cout, generator=gen).to(BF16).to(_dev())
+    whole = ops.conv_wgrad(xd, 0, cin, dyd, cout, 3, 1, 1)
+    lim = 3 * H * W * cout * 2 + 1                       # three images of the larger tensor (dy) fit, four do not
+    sliced = ops.conv_wgrad(xd, 0, cin, dyd, cout, 3, 1, 1, _limit=lim)
+    again = ops.conv_wgrad(xd, 0, cin, dyd, cout, 3, 1, 1, _limit=lim)
+    by_hand = (ops.conv_wgrad(xd[0:3], 0, cin, dyd[0:3], cout, 3, 1, 1) + ops.conv_wgrad(xd[3:6], 0, cin, dyd[3:6], cout, 3, 1, 1)
+               + ops.conv_wgrad(xd[6:7], 0, cin, dyd[6:7], cout, 3, 1, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(sliced, again) and torch.equal(sliced, by_hand)
+    scale = float(whole.abs().max())
+    assert float((sliced - whole).abs().max()) <= 2e-5 * scale           # same sums, another f32 order
+    with pytest.raises(Exception, match="one image exceeds"):
+        ops.conv_wgrad(xd, 0, cin, dyd, cout, 3, 1, 1, _limit=100)
+
+
 @pytest.mark.parametrize("cout,cin,ks", [(64, 64, 3), (128, 64, 3), (64, 256, 1), (512, 256, 3), (32, 1024, 3)])
 def test_pack_conv_weights_equals_the_torch_permutes(cout, cin, ks):
     from multiagentperception_amd import ops
