@@ -12,8 +12,9 @@ SO = os.environ.get("W2C_STEM_SO", os.path.join(ROOT, "tools", "libw2c_stem_phas
 
 def build():
     src = os.path.join(ROOT, "multiagentperception_amd", "csrc", "stem.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DW2C_STEM_TIMING", src, "-o", SO])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DW2C_STEM_TIMING"]
+                          + os.environ.get("W2C_STEM_DEFS", "").split()
+                          + ["-x", "hip", src, os.path.join(ROOT, "tools", "ubench", "options_stub.cpp"), "-o", SO])
 
 
 def main():
