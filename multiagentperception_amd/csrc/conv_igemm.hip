@@ -70,6 +70,15 @@ extern "C" int w2c_debug_conv_span(void* slot) {
     return W2C_OK;
 }
 
+// A/B switch (compile time): with -DW2C_AGPR_FORM the ring / patch kernels carry one dummy "a"-constrained asm operand, which makes the
+// backend select the AGPR form of every builtin MFMA in them (accumulators in AGPRs, 128 + 128 register split) instead of the VGPR form
+// it picks for kernels budgeted for <= 256 registers.  Why it matters: tools/ubench/coissue.hip.
+#ifdef W2C_AGPR_FORM
+#define W2C_FORCE_AGPR_FORM() asm volatile("" ::"a"(0))
+#else
+#define W2C_FORCE_AGPR_FORM() do {} while (0)
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -178,6 +187,7 @@ __device__ __forceinline__ void pipeline_barrier() {
 template <int BM, int BN, int WM, int WN, int BK, int STAGES, bool SPLITK = false, bool F8 = false, bool DUAL = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
+    W2C_FORCE_AGPR_FORM();
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;        // wave tile
     constexpr int MI = WTM / 32, NI = WTN / 32;        // 32x32 MFMA tiles per wave
@@ -581,6 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
 template <int TH, int TW, int BN, int WM, int WN, int STAGES, int PB, bool F8 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
+    W2C_FORCE_AGPR_FORM();
     constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;  // operand bytes per element / channels per 128-byte K-step
     constexpr int BM = TH * TW;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -944,6 +955,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
 template <int BN, int RS, bool F8>
 __global__ __launch_bounds__(512) void conv3x3s2_patch_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    W2C_FORCE_AGPR_FORM();
     constexpr int ES = OpT<F8>::ES, CK = OpT<F8>::CK;
     constexpr int TH = 8, TW = 16, BM = TH * TW, WM = 4, WN = 2, NW = 8, NT = 512;
     constexpr int D = RS - 1;                                          // weight tile t+D is issued at step t
