@@ -315,6 +315,80 @@ def test_training_step_on_hip_convs_matches_stock_autograd(arch, n, query):
           "backward is not deterministic)" % (sum(same), len(same)))
 
 
+def _conditioned(model, arch, x, score_sigma=1.5, logit_gain=30.0):
+    """A 'trained-like' weight set from the filler one: peaked class logits (decoder read-out x logit_gain: sigma 0.1 -> ~3) and
+    attention scores of order 1 (the key head's last layer scaled so that the scores of THIS batch have the given sigma) -- with the
+    raw filler weights the scores reach 8.5 (when2com) / 30 (who2com without a query net), the softmax is one-hot and the gradient
+    of everything in front of it is chaotic even between two f32 runs."""
+    from multiagentperception_amd import train_ops
+    with torch.no_grad():
+        model.decoder.output_decoder.pred[2].weight.mul_(logit_gain)
+        model.decoder.output_decoder.pred[2].bias.mul_(logit_gain)
+        train_ops.set_train_backend("stock")
+        prob = model(x, training=True, MO_flag=True)[1]                  # prob_action [B, N keys, N queries]: softmax over the keys
+        # scores are not returned: estimate their spread from the softmax -- log-odds of the attention weights
+        lo = torch.log(prob.clamp_min(1e-30))
+        sigma = float((lo - lo.mean(dim=1, keepdim=True)).std())
+        scale = score_sigma / max(sigma, 1e-6)
+        model.key_net.fc[4].weight.mul_(scale)
+        model.key_net.fc[4].bias.mul_(scale)
+    return sigma, scale
+
+
+@pytest.mark.parametrize("arch,query", [("MIMOcom", True), ("MIMOcomWho", False)])
+def test_training_step_gradient_direction_on_a_conditioned_weight_set(arch, query):
+    """The DIRECTION of a whole training step's gradient, value path and policy path separately (the step test
+    above is relative to stock bf16 and says nothing about the parameters behind the attention).  Weights conditioned like a trained
+    net's (_conditioned): the gradient of the HIP step must point where the all-f32 stock step's gradient points -- cosine per
+    parameter group -- and a sign error anywhere behind the attention would show as a negative cosine of the policy group."""
+    from oracle import filler
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import train_ops
+    from multiagentperception_amd.loss import cross_entropy2d
+    n, b, s = 3, 2, 128
+    torch.manual_seed(0)
+    model = get_model(_cfg(arch, n, s, query), 11)
+    filler.apply_to_module(model)
+    model = model.to(_dev()).train()
+    x = torch.from_numpy(filler.synthetic_frames(b, n, s, s, 57)).to(_dev())
+    labels = torch.from_numpy(filler.synthetic_labels(b * n, s, s, 57)).to(_dev())
+    sigma, scale = _conditioned(model, arch, x)
+    grads = {}
+    for backend in ("stock", "hip", "hip#2"):
+        train_ops.set_train_backend(backend.split("#")[0])
+        model.zero_grad()
+        out = model(x, training=True, MO_flag=True)
+        loss = cross_entropy2d(input=out[0], target=labels) if backend != "stock" else F.cross_entropy(out[0], labels, ignore_index=250)
+        loss.backward()
+        grads[backend] = (float(loss.detach()), {k: p.grad.detach().double().cpu().reshape(-1).clone() for k, p in model.named_parameters()
+                                                 if p.grad is not None})
+    train_ops.set_train_backend("hip")
+
+    def group(k):
+        if k.startswith("u_encoder.") or k.startswith("decoder."):
+            return "value"
+        return "policy"                           # query_key_net.*, key_net.*, query_net.*, attention_net.*
+
+    def cos(a, b, which):
+        dot = na = nb = 0.0
+        for k in grads[a][1]:
+            if group(k) == which:
+                u, v = grads[a][1][k], grads[b][1][k]
+                dot += float(torch.dot(u, v)); na += float(u.norm() ** 2); nb += float(v.norm() ** 2)
+        return dot / (na ** 0.5 * nb ** 0.5 + 1e-300), nb ** 0.5
+
+    cv, nv = cos("hip", "stock", "value")
+    cp, npol = cos("hip", "stock", "policy")
+    rv, _ = cos("hip", "hip#2", "value")
+    rp, _ = cos("hip", "hip#2", "policy")
+    print("%s: score sigma %.2f -> x%.3f | loss f32 %.4f hip %.4f | cosine hip vs f32: value path %.4f (|g| %.3e)  policy path %.4f (|g| %.3e)"
+          " | hip vs hip again: %.6f %.6f" % (arch, sigma, scale, grads["stock"][0], grads["hip"][0], cv, nv, cp, npol, rv, rp))
+    assert abs(grads["hip"][0] - grads["stock"][0]) <= 3e-2 * abs(grads["stock"][0])
+    assert rv > 0.999999 and rp > 0.999999                        # the HIP step is reproducible
+    assert cv >= 0.90, cv                                         # bf16 activation storage costs 0.03-0.08 of cosine (see the test above)
+    assert npol > 0 and cp >= 0.70, cp                            # same direction behind the attention softmax
+
+
 @pytest.mark.parametrize("M,H,W", [(2, 64, 64), (3, 32, 128), (1, 128, 64)])
 def test_stem_conv_training_forward_and_weight_gradient_match_f64(M, H, W):
     """conv1 (3 -> 64, 7x7 / 2 / pad 3) of the trunk in training: w2c_stem_conv7x7_train_bf16 for the forward,
