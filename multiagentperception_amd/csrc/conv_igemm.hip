@@ -1560,6 +1560,302 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw_kernel(ConvArgs p) {
 }
 
 template <bool HAS_RES>
+__global__ __launch_bounds__(256) void conv3x3_c64_regw2_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PW = 18;                         // patch width (16 + 2 halo); 6 rows
+    constexpr int PATCH_BYTES = 14 * 1024;         // 14 DMA instructions x 8 pixels x 128 B (108 pixels used)
+    constexpr int RES_BYTES = 8 * 1024;            // 64 pixels x 128 B
+    constexpr int WAVE_LDS = 2 * PATCH_BYTES + RES_BYTES;
+    constexpr int SPITCH = 272;                    // staging row pitch, bytes
+    constexpr int WPITCH = 1152 + 16;              // prologue weight rows in LDS: 16-B pad => conflict-free fragment reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int g = blockIdx.y;
+    char* const wl = smem + wave * WAVE_LDS;
+    char* const resbuf = wl + 2 * PATCH_BYTES;
+
+    // ---- weights -> registers: A operand, row = output channel, k = (tap, cin).  The register CLASS is pinned by the
+    // inline-asm MFMAs below: channel tile 0 (144 regs) + the 64 accumulators live in AGPRs, channel tile 1 in VGPRs.
+    // Left to the compiler, all 288 land in VGPR-class values that are spilled to / re-read from AGPRs around every use
+    // and the B-fragment reads lose their double buffer (measured 102 us vs 72 us for the ring kernel).
+    // A fragment is 16 B out of a 1152-B weight row: gathering it straight from global memory costs 72 uncoalesced
+    // loads per lane, so the group's 73 KB go through LDS once (coalesced in, fragment-shaped out). ----
+    const unsigned long long wall0 = p.dbg ? wall_clock64() : 0;
+    span_stamp(p, false);
+    u32x4_t wa[9][4], wv[9][4];
+    {
+        const uint16_t* wg = p.w + (size_t)g * 64 * 576;
+        for (int c = tid; c < 64 * 72; c += 256) {
+            const int row = c / 72, col = c - row * 72;
+            *reinterpret_cast<uint4*>(smem + row * WPITCH + col * 16) = *reinterpret_cast<const uint4*>(wg + row * 576 + col * 8);
+        }
+        if (tid < 64) {
+            // BN scale / shift of the group in the accumulators' layout: entry (ct, j, lhi) = {scale[4], shift[4]} of channels
+            // ct*32 + 8j + 4 lhi .. +3 -- what one lane half holds in accumulator elements 4j .. 4j+3 of channel tile ct
+            const int ct = tid >> 5, j = (tid >> 3) & 3, lh = (tid >> 2) & 1, k = tid & 3;
+            float* const e = reinterpret_cast<float*>(smem + 4 * WAVE_LDS) + ((ct * 4 + j) * 2 + lh) * 8;
+            e[k] = p.scale[g * 64 + tid];
+            e[4 + k] = p.shift[g * 64 + tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                wa[tap][kc] = *reinterpret_cast<const u32x4_t*>(smem + l31 * WPITCH + tap * 128 + kc * 32 + lhi * 16);
+                wv[tap][kc] = *reinterpret_cast<const u32x4_t*>(smem + (32 + l31) * WPITCH + tap * 128 + kc * 32 + lhi * 16);
+            }
+        __syncthreads();                           // the only workgroup barriers of the kernel: LDS is reused below
+    }
+
+    // ---- tiles of this wave: a contiguous run, XCD-contiguous across the grid ----
+    const int ntx = p.W >> 4, nty = p.H >> 2, tpi = ntx * nty;
+    const int T = p.M * tpi;
+    const int nwg = gridDim.x;
+    const int b = blockIdx.x;
+    const int logical = (nwg % 8 == 0) ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
+    const int wid = logical * 4 + wave, nw = nwg * 4;
+    const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long)wid * T) / nw));      // wave-uniform, and the
+    const int t_end = __builtin_amdgcn_readfirstlane((int)(((long)(wid + 1) * T) / nw));    // compiler should know it
+    if (t_begin >= t_end) return;
+
+    // ---- DMA constants.  Patch instruction j moves pixels q = 8j + lane/8 (q = row*18 + col), lane%8 = LDS chunk
+    // position; the bank swizzle (chunk c of a pixel in patch column x sits at c ^ ((x>>1)&7)) is applied to the SOURCE chunk. ----
+    const size_t x_bytes = (size_t)p.M * p.H * p.W * p.xcs * 2;
+    const size_t y_bytes = (size_t)p.M * p.H * p.W * p.ycs * (p.y_f32 ? 4 : 2);
+    const size_t r_bytes = (size_t)p.M * p.H * p.W * p.ycs * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.x + (size_t)g * 64), 0, (int)(x_bytes - (size_t)g * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>((HAS_RES ? p.res : p.x) + (size_t)g * 64), 0, (int)((HAS_RES ? r_bytes : x_bytes) - (size_t)g * 128),
+        0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)y_bytes, 0x00020000);
+    int off_rel[14];
+    unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_inval = 0;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const int q = 8 * j + (lane >> 3);
+        const int dy = (q * 3641) >> 16, dx = q - dy * PW;          // q / 18, q % 18 for q < 128
+        const int chunk = (lane & 7) ^ ((dx >> 1) & 7);             // swizzle keyed on the patch COLUMN (conflict-free, see above)
+        off_rel[j] = ((dy * p.W + dx) * p.xcs + chunk * 8) * 2;
+        m_top |= (dy == 0 ? 1u : 0u) << j;
+        m_bot |= (dy == 5 ? 1u : 0u) << j;
+        m_left |= (dx == 0 ? 1u : 0u) << j;
+        m_right |= (dx == 17 ? 1u : 0u) << j;
+        m_inval |= (q >= 6 * PW ? 1u : 0u) << j;
+    }
+    // residual DMA: instruction j moves pixels 8j .. 8j+7 (pixel lane/8), 16-byte chunk c of pixel q lands at position c ^ f(q),
+    // f(q) = (q & 7) ^ ((q >> 3) & 1) = (lane/8) ^ (j & 1) -- keyed so that the epilogue's 8-byte reads (one pixel per lane, same channel
+    // quad: rows 128 B apart) spread over the banks instead of hitting two of them
+    const unsigned r_lane0 = (unsigned)(((lane >> 3) * p.ycs + ((lane & 7) ^ (lane >> 3)) * 8) * 2);
+    const unsigned r_lane1 = (unsigned)(((lane >> 3) * p.ycs + ((lane & 7) ^ (lane >> 3) ^ 1) * 8) * 2);
+    // epilogue, register-direct: lane (l31, lhi) holds pixel (2pt + l31/16, l31%16) of the tile; after the half-wave swap it stores the
+    // 8 channels ct*32 + 8(2jp + lhi) .. +7 of that pixel
+    const int e_px = (l31 >> 4) * p.W + (l31 & 15);                                        // + 2 pt W
+    const unsigned y_lane = (unsigned)((e_px * p.ycs + g * 64 + lhi * 8) * 2);
+    const int r_px = (l31 >> 4) * 16 + (l31 & 15);                                         // + 32 pt: pixel index in the residual tile
+    const int r_f = (r_px & 7) ^ ((r_px >> 3) & 1);                                        // f(q) of the DMA above (+ 32 pt does not change it)
+
+    auto tile_coords = [&](int t, int& img, int& y0, int& x0) {
+        img = t / tpi;
+        const int r = t - img * tpi;
+        const int tx = r / nty;                    // column-major: a wave's consecutive tiles are vertically adjacent, so
+        x0 = tx * 16;                              // 2 of the 6 patch rows of the next tile were just read by this wave
+        y0 = (r - tx * nty) * 4;                   // (measured: layer1 L2-miss read traffic 1.47x -> see profiles/)
+    };
+    // patch DMA of one tile = 14 instructions; `pbase` / `pbad` are its wave-uniform base offset and halo mask
+    int pbase = 0;
+    unsigned pbad = 0;
+    auto patch_setup = [&](int t, bool live) {
+        int img, y0, x0;
+        tile_coords(t, img, y0, x0);
+        pbase = (((img * p.H + y0 - 1) * p.W) + x0 - 1) * p.xcs * 2;          // bytes; negative only where the halo lanes are off
+        pbad = !live ? 0xFFFFFFFFu
+                     : (m_inval | (y0 == 0 ? m_top : 0u) | (y0 + 4 == p.H ? m_bot : 0u) | (x0 == 0 ? m_left : 0u) |
+                        (x0 + 16 == p.W ? m_right : 0u));
+    };
+    auto patch_piece = [&](int j, char* dst) {
+        const unsigned vo = ((pbad >> j) & 1u) ? 0x80000000u : (unsigned)(pbase + off_rel[j]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, W2C_LPTR(dst + j * 1024), 16, vo, 0, 0, 0);
+    };
+    int rbase = 0;
+    auto residual_piece = [&](int j) {       // instruction j: pixels 8j..8j+7 of the 4 x 16 tile (row j/2, cols 8(j&1)..)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, W2C_LPTR(resbuf + j * 1024), 16, (j & 1) ? r_lane1 : r_lane0,
+                                                 rbase + ((j >> 1) * p.W + 8 * (j & 1)) * p.ycs * 2, 0, 0);
+    };
+
+    // B-fragment geometry: MFMA pixel tile pt = rows 2pt, 2pt+1 of the 4 x 16 tile; lane's pixel = (l31>>4, l31&15)
+    int qb[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) qb[pt] = (pt * 2 + (l31 >> 4)) * PW + (l31 & 15);
+    const char* const ssd = smem + 4 * WAVE_LDS + lhi * 32;    // + (ct*4 + j) * 64: {scale[4], shift[4]} of this lane half's quad
+
+    int cur = 0;
+    patch_setup(t_begin, true);
+#pragma unroll
+    for (int j = 0; j < 14; ++j) patch_piece(j, wl);
+    unsigned long long ph[4] = {0, 0, 0, 0};       // debug (p.dbg): cycles at tile top | MFMA loop | vmcnt wait | epilogue
+    const unsigned long long wall1 = p.dbg ? wall_clock64() : 0;
+    long long tp = p.dbg ? clock64() : 0;
+    auto stamp = [&](int i) {
+        if (p.dbg) { const long long n = clock64(); ph[i] += (unsigned long long)(n - tp); tp = n; }
+    };
+    int img, y0, x0;
+    tile_coords(t_begin, img, y0, x0);
+    for (int t = t_begin; t < t_end; ++t) {
+        char* const pc = wl + cur * PATCH_BYTES;
+        char* const pn = wl + (cur ^ 1) * PATCH_BYTES;
+        // tile t -> (img, y0, x0) incrementally (the divisions of tile_coords cost ~500 cycles per tile on one wave)
+        if (t != t_begin) {
+            y0 += 4;
+            if (y0 == p.H) { y0 = 0; x0 += 16; if (x0 == p.W) { x0 = 0; ++img; } }
+        }
+        rbase = ((img * p.H + y0) * p.W + x0) * p.ycs * 2;
+        {   // patch(t+1): base offset + halo mask; on the last tile every lane is off (zeros into the idle buffer)
+            int xn = x0, yn = y0 + 4, in = img;
+            if (yn == p.H) { yn = 0; xn += 16; if (xn == p.W) { xn = 0; ++in; } }
+            const bool live = t + 1 < t_end;
+            pbase = (((in * p.H + yn - 1) * p.W) + xn - 1) * p.xcs * 2;
+            pbad = !live ? 0xFFFFFFFFu
+                         : (m_inval | (yn == 0 ? m_top : 0u) | (yn + 4 == p.H ? m_bot : 0u) | (xn == 0 ? m_left : 0u) |
+                            (xn + 16 == p.W ? m_right : 0u));
+        }
+        // patch(t) must have landed.  First tile: everything issued so far.  Later tiles: its 14 pieces were issued during
+        // tile t-1 and are older than that tile's output stores (8, or 16 for f32 output), which may stay in flight --
+        // vmcnt retires in issue order on gfx9 (the compiler's own waitcnt insertion relies on the same).
+        if (t == t_begin) wait_vmcnt<0>();
+        else if (p.y_f32) wait_vmcnt<16>();
+        else wait_vmcnt<8>();
+        asm volatile("" ::: "memory");
+        stamp(0);
+
+        // 36 K-steps (tap, 16-channel chunk), fully unrolled; the B fragments of step s+1 are read before the MFMAs of
+        // step s are issued, and the 8 + 14 LDS-DMA instructions of residual(t) / patch(t+1) are spread one per K-step
+        // through the MFMA stream (issued back to back at the tile top they cost ~95 cycles each with the MFMA pipe idle).
+        f32x16_t acc[2][2];
+        // fragment address of (tap, kc) for pixel q = qb + ky*18 + kx:  q*128 + ((2kc | lhi) ^ ((q>>1)&7))*16
+        //                                                             = fb + ((kc << 5) ^ fx),  fb, fx per (tap, pt).
+        // qv is laundered through an empty asm once per tile so the 72 addresses are NOT hoisted out of the tile loop
+        // (they would cost 72 registers; recomputed they are ~2 VALU per read in the MFMA shadow).
+        int qv0 = qb[0], qv1 = qb[1];
+        asm volatile("" : "+v"(qv0), "+v"(qv1));
+        int fb[2], fx[2];
+        auto tap_setup = [&](int tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int q0 = qv0 + ky * PW + kx, q1 = qv1 + ky * PW + kx;
+            const int cs = ((((l31 & 15) + kx) >> 1) ^ lhi) & 7;      // column-keyed swizzle, both pixel tiles share the column
+            fb[0] = q0 * 128; fx[0] = cs << 4;
+            fb[1] = q1 * 128; fx[1] = cs << 4;
+        };
+        auto frag = [&](int kc, int pt) { return *reinterpret_cast<const u32x4_t*>(pc + fb[pt] + ((kc << 5) ^ fx[pt])); };
+        u32x4_t bx[2][2];
+        tap_setup(0);
+        bx[0][0] = frag(0, 0);
+        bx[0][1] = frag(0, 1);
+#pragma unroll
+        for (int step = 0; step < 36; ++step) {
+            const int tap = step >> 2, kc = step & 3, cb = step & 1;
+            if (step + 1 < 36) {
+                if (((step + 1) & 3) == 0) tap_setup((step + 1) >> 2);
+                bx[cb ^ 1][0] = frag((step + 1) & 3, 0);
+                bx[cb ^ 1][1] = frag((step + 1) & 3, 1);
+            }
+            if (HAS_RES && step >= 1 && step <= 8) residual_piece(step - 1);
+            if (step >= 9 && step <= 22) patch_piece(step - 9, pn);
+            if (step == 0) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[0][0]) : "a"(wa[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[0][1]) : "v"(wv[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[1][0]) : "a"(wa[tap][kc]), "v"(bx[cb][1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[1][1]) : "v"(wv[tap][kc]), "v"(bx[cb][1]));
+            } else {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0][0]) : "a"(wa[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0][1]) : "v"(wv[tap][kc]), "v"(bx[cb][0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[1][0]) : "a"(wa[tap][kc]), "v"(bx[cb][1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[1][1]) : "v"(wv[tap][kc]), "v"(bx[cb][1]));
+            }
+        }
+        // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> VALU/DS-read wait states by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        stamp(1);
+
+        // ---- epilogue, register-direct: no LDS staging.  Per (pixel tile pt, channel tile ct) the lane's four channel quads are
+        // scaled / shifted (+ residual, read as 8 bytes per quad), rounded to bf16, ReLU'd on the packed pairs, and v_permlane32_swap
+        // pairs quad j of the lower half-wave with quad j of the upper one (and quad j+1 likewise), so that every lane ends up with 8
+        // consecutive channels of its pixel = one 16-byte store.  Same arithmetic, same order as the staged form: same bits. ----
+        if (HAS_RES) {
+            asm volatile("" ::: "memory");
+            wait_vmcnt<14>();                      // residual(t) landed; the 14 younger pieces of patch(t+1) may still be in flight
+            asm volatile("" ::: "memory");
+        }
+        stamp(2);
+        const int tile_pix = (img * p.H + y0) * p.W + x0;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const char* const rrow = resbuf + (pt * 32 + r_px) * 128 + lhi * 8;
+            const int so = (tile_pix + 2 * pt * p.W) * p.ycs * 2;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                // one accumulator tile out of the AGPRs at a time: this (empty, volatile, memory-clobbering) asm "rewrites" the tile,
+                // so its 16 reads cannot be hoisted above the previous tile's stores -- all 64 at once do not fit the 256 VGPRs
+                asm volatile("" : "+a"(acc[pt][ct])::"memory");
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    uint32_t pk[2][2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * jp + jj;
+                        const f32x4_t scv = *reinterpret_cast<const f32x4_t*>(ssd + (ct * 4 + j) * 64);
+                        const f32x4_t shv = *reinterpret_cast<const f32x4_t*>(ssd + (ct * 4 + j) * 64 + 16);
+                        f32x4_t a = f32x4_t{acc[pt][ct][j * 4], acc[pt][ct][j * 4 + 1], acc[pt][ct][j * 4 + 2], acc[pt][ct][j * 4 + 3]} * scv + shv;
+                        if constexpr (HAS_RES) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(rrow + (((ct * 4 + j) ^ r_f) << 4));
+                            a += f32x4_t{__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xFFFF0000u),
+                                         __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xFFFF0000u)};
+                        }
+                        if (p.y_f32) {             // f32 output (tests, the decoder head's shape never comes here): the quad as it is
+                            if (p.relu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a), rs_y,
+                                                                   (unsigned)((e_px * p.ycs + g * 64 + ct * 32 + 8 * j + 4 * lhi) * 4),
+                                                                   (tile_pix + 2 * pt * p.W) * p.ycs * 4, 0);
+                            continue;
+                        }
+                        pk[jj][0] = pack_bf16x2(a[0], a[1]);
+                        pk[jj][1] = pack_bf16x2(a[2], a[3]);
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const s16x2_t h = __builtin_bit_cast(s16x2_t, pk[jj][e]);
+                                pk[jj][e] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(h, s16x2_t{0, 0}));
+                            }
+                        }
+                    }
+                    if (p.y_f32) continue;
+                    const auto sa = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto sb = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    const u32x4_t o = {sa[0], sb[0], sa[1], sb[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, y_lane + (ct * 32 + jp * 16) * 2, so, 0);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        stamp(3);
+        cur ^= 1;
+    }
+    if (p.dbg && lane == 0 && wave == 0) {         // 8 x u64 per workgroup: 4 phase sums (shader cycles), 3 wall stamps (100 MHz)
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = ph[i];
+        d[4] = wall0; d[5] = wall1; d[6] = wall_clock64(); d[7] = 1;
+    }
+    span_stamp(p, true);
+#endif
+}
+
+template <bool HAS_RES, int VER = 1>
 int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int lds = 4 * (2 * 14 * 1024 + 8 * 1024) + 512;    // 4 waves' patch/residual buffers + scale/shift
     static unsigned long long attr_mask = 0;
@@ -1567,7 +1863,8 @@ int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
     (void)hipGetDevice(&dev);
     static int n_cu[64] = {0};
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_regw_kernel<HAS_RES>),
+        (void)hipFuncSetAttribute(VER == 2 ? reinterpret_cast<const void*>(&conv3x3_c64_regw2_kernel<HAS_RES>)
+                                           : reinterpret_cast<const void*>(&conv3x3_c64_regw_kernel<HAS_RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipDeviceProp_t prop;
         n_cu[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1578,8 +1875,15 @@ int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
     int wgs = (n_cu[dev & 63] + groups - 1) / groups;            // one 4-wave workgroup per CU, split over the groups
     wgs = (wgs + 7) / 8 * 8;
     if ((long)wgs * 4 > tiles) wgs = (int)((tiles + 3) / 4);
-    hipLaunchKernelGGL((conv3x3_c64_regw_kernel<HAS_RES>), dim3(wgs, groups), dim3(256), lds, s, a);
+    if (VER == 2) hipLaunchKernelGGL((conv3x3_c64_regw2_kernel<HAS_RES>), dim3(wgs, groups), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_c64_regw_kernel<HAS_RES>), dim3(wgs, groups), dim3(256), lds, s, a);
     return w2c_launch_status();
+}
+
+int launch_regw2_any(ConvArgs& a, int groups, hipStream_t s) {       // register-direct epilogue
+    if (a.ks != 3 || a.stride != 1 || a.Cin != 64 || a.Cout != 64 || a.H % 4 != 0 || a.W % 16 != 0 || a.ygs != 64 || a.y8 || !a.y) return W2C_E_ARG;
+    if ((size_t)a.M * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.M * a.H * a.W * a.ycs * 2 >= (1ull << 31)) return W2C_E_ARG;
+    return a.res ? launch_regw<true, 2>(a, groups, s) : launch_regw<false, 2>(a, groups, s);
 }
 
 int launch_regw_any(ConvArgs& a, int groups, hipStream_t s) {
@@ -1951,6 +2255,7 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
+        case 52: return launch_regw2_any(a, groups, s);
         // stride-2 3x3 on polyphase halo patches (here without the fused downsample)
         case 60: return launch_s2patch<64, 3, false>(a, groups, s);
         case 61: return launch_s2patch<128, 2, false>(a, groups, s);

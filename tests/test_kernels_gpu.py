@@ -141,6 +141,9 @@ VARIANT_CASES = [
     # layer1 register-resident-weights kernel: borders on every side, single-tile images, both groups, +/- residual
     (50, 3, 16, 32, 64, 64, 3, 1, 2, True), (50, 2, 4, 16, 64, 64, 3, 1, 1, False), (50, 5, 12, 48, 64, 64, 3, 1, 2, False),
     (50, 1, 64, 64, 64, 64, 3, 1, 1, True),
+    # ... and its register-direct-epilogue form (no LDS staging: half-wave swap into 16-byte stores, swizzled residual tile)
+    (52, 3, 16, 32, 64, 64, 3, 1, 2, True), (52, 2, 4, 16, 64, 64, 3, 1, 1, False), (52, 5, 12, 48, 64, 64, 3, 1, 2, False),
+    (52, 1, 64, 64, 64, 64, 3, 1, 1, True),
 ]
 
 
@@ -233,7 +236,7 @@ def test_conv_splitk_matches_fp32_and_is_deterministic(case, lib_option):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
 
 
-@pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128),
+@pytest.mark.parametrize("variant,cin,cout,hw", [(30, 128, 128, 64), (36, 64, 64, 128), (38, 64, 64, 128), (50, 64, 64, 128), (52, 64, 64, 128),
                                                  (36, 256, 256, 32), (0, 128, 128, 64), (6, 256, 256, 16)])
 def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw):
     """Regression for a WAR race of the LDS pipeline: a raw s_barrier let waves pass with fragment reads still in
@@ -255,6 +258,26 @@ def test_conv_pipeline_is_race_free_under_full_occupancy(variant, cin, cout, hw)
     torch.cuda.synchronize()
     # every kernel walks K as (64-channel chunk, tap) and issues the same MFMA sequence per output: bit-identical
     assert torch.equal(first, ref)
+
+
+def test_layer1_kernel_forms_are_bit_identical_with_residual_and_relu():
+    """variant 52 (register-direct epilogue) against variant 50 (f32 LDS staging) and the ring kernel, with a residual, a non-trivial
+    scale / shift and ReLU: same MFMA sequence, same epilogue arithmetic in the same order -> torch.equal."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(52)
+    M, G, hw = 6, 2, 64
+    x = torch.randn(M, hw, hw, G * 64, generator=gen).to(BF16).to(_dev())
+    r = torch.randn(M, hw, hw, G * 64, generator=gen).to(BF16).to(_dev())
+    w = (torch.randn(G, 64, 9 * 64, generator=gen) * 0.06).to(BF16).to(_dev())
+    sc = (torch.rand(G * 64, generator=gen) + 0.5).to(_dev())
+    sh = (torch.randn(G * 64, generator=gen) * 0.3).to(_dev())
+    for res in (r, None):
+        for relu in (True, False):
+            a = ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, relu=relu, variant=50)
+            b = ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, relu=relu, variant=52)
+            c = ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, relu=relu, variant=38)
+            torch.cuda.synchronize()
+            assert torch.equal(a, c) and torch.equal(b, a), (res is not None, relu)
 
 
 @pytest.mark.parametrize("cin,cout,hw,stride,ks", [(64, 64, 32, 1, 3), (128, 128, 32, 1, 3), (256, 128, 16, 1, 3), (512, 512, 16, 1, 3),

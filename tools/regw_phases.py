@@ -9,7 +9,7 @@ from multiagentperception_amd import ops, _native  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    C, H = (64, 128) if variant == 50 else (128, 64)
+    C, H = (64, 128) if variant in (50, 52) else (128, 64)
     M, W, G = 20, H, 2
     x = torch.randn(M, H, W, G * C, device=dev).to(torch.bfloat16)
     w = (torch.randn(G, C, 9 * C, device=dev) * 0.05).to(torch.bfloat16)
@@ -30,7 +30,7 @@ def main():
         print("   wall (us): kernel start spread %.1f | prologue mean %.1f | tile loop mean %.1f max %.1f | last end %.1f" % (
             wl[:, 0].max(), (wl[:, 1] - wl[:, 0]).mean(), (wl[:, 2] - wl[:, 1]).mean(), (wl[:, 2] - wl[:, 1]).max(), wl[:, 2].max()))
         b = full[:, :4].double()
-        tiles = M * (H // 4) * (W // 16) * G / (b.shape[0] * (4 if variant == 50 else 1))
+        tiles = M * (H // 4) * (W // 16) * G / (b.shape[0] * (4 if variant in (50, 52) else 1))
         print("residual=%s: %d workgroups, %.1f tiles/wave; cycles per tile: DMA issue %.0f | MFMA loop %.0f (pure 4608) | "
               "vmcnt wait %.0f | epilogue %.0f | total %.0f" % (res is not None, b.shape[0], tiles, *(b.mean(0) / tiles).tolist(),
                                                                  b.sum(1).mean() / tiles))
