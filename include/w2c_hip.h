@@ -112,6 +112,26 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
                                 void* y, int y_cstride, int y_is_f32,
                                 const void* zero_page, int variant, long long y_group_stride, w2c_stream_t stream);
 
+/* ---- K2w: 3x3 / stride-1 / pad-1 convolution, "weights to registers" form (csrc/conv_wreg.inl) -- the BasicBlock and policy /
+ * decoder convs on maps of at least 8 x 16 pixels with Cin >= 256 (backbone.py:66-69 layer3 / layer4, agent.py:126-127,
+ * backbone.py:150): same operation and epilogue as w2c_conv_igemm_bf16 (y = relu?(conv * scale + shift (+ residual)), bf16
+ * NHWC, groups side by side or y_group_stride apart), different schedule: 128-pixel x 64-channel wave tiles, K split over the
+ * waves of a workgroup, weights loaded straight into registers from a fragment-ordered copy.  Results agree with
+ * w2c_conv_igemm_bf16 to f32 summation order (the K groups' partial sums are added at the end), not bit for bit; they are
+ * independent of M (one workgroup per 8 x 16-pixel tile, fixed order).
+ *   w2c_pack_wfrag_bf16      : w [groups][Cout][9*Cin] (the layout w2c_conv_igemm_bf16 reads) -> wfrag, same size, on the device
+ *   w2c_conv3x3_wreg_supported: 1 when the shape is supported AND the library prefers this kernel for it (a function of the
+ *                               layer geometry only, never of M), else 0
+ *   w2c_conv3x3_wreg_bf16    : form 0 = the library's choice; 80 / 81 / 83 = 2x2 / 1x4 / 1x2 waves (channel blocks x K groups).
+ * Requires H % 8 == 0, W % 16 == 0, Cin % 64 == 0, Cout % 64 == 0 (form 80: % 128), 16-byte aligned rows. */
+int w2c_pack_wfrag_bf16(const uint16_t* w, uint16_t* wfrag, int groups, int Cout, int Cin, w2c_stream_t stream);
+int w2c_conv3x3_wreg_supported(int H, int W, int Cin, int Cout);
+int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                          const uint16_t* wfrag, int Cout, int groups,
+                          const float* scale, const float* shift,
+                          const uint16_t* residual, int relu,
+                          uint16_t* y, int y_cstride, long long y_group_stride, int form, w2c_stream_t stream);
+
 /* Split-K form of K2 for the tail layers (policy_net4 conv3..5 agent.py:128-132, simple_decoder's last conv
  * backbone.py:152): few output tiles under a long weight-streaming K loop.  `ksplit` workgroups share a tile, each
  * summing a contiguous range of K-steps into `workspace` (f32 partial tiles); a second launch adds them in split

@@ -31,6 +31,9 @@ SIGNATURES = {
     "w2c_conv_igemm_bf16_splitk": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i,
                                    _vp, _ll, _ll, _vp],
     "w2c_conv_splitk_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "w2c_pack_wfrag_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "w2c_conv3x3_wreg_supported": [_i, _i, _i, _i],
+    "w2c_conv3x3_wreg_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _vp],
     "w2c_debug_conv_timeline": [_vp],
     "w2c_debug_stamp": [_vp, _vp],
     "w2c_debug_conv_span": [_vp],

@@ -1924,6 +1924,8 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     return w2c_launch_status();
 }
 
+#include "conv_wreg.inl"
+
 template <int BM, int BN, int BK, int STAGES>
 constexpr int conv_lds_bytes() {
     constexpr int ring = STAGES * (BM + BN) * BK * 2;
@@ -2253,6 +2255,17 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 36: return launch_patch<8, 16, 64, 4, 2, 3>(a, groups, s);      // 8 waves, 64 channels, 3-deep weight ring
         // Cin == 64 (one channel chunk): a single patch buffer -> ~39 KB of LDS -> four workgroups per CU
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
+        // round-3 experiment: 128-pixel x 64-channel WAVE tiles (6 ds_read_b128 per 8 MFMAs instead of 4 per 4 / 2 per 1)
+        case 72: return launch_patch<16, 16, 128, 2, 2, 3>(a, groups, s);    // 4 waves, 256 px x 128 ch, one workgroup per CU
+        case 73: return launch_patch<8, 16, 128, 1, 2, 2>(a, groups, s);     // 2 waves, 128 px x 128 ch, two workgroups per CU
+        case 74: return launch_patch<8, 16, 128, 1, 2, 3>(a, groups, s);     // 2 waves, 3-deep ring (one workgroup per CU)
+        // weights-to-registers kernels (conv_wreg.inl; `w` must be in w2c_pack_wfrag order): NN channel blocks x KS K groups
+        case 80: return launch_wreg<2, 2>(a, groups, s);
+        case 81: return launch_wreg<1, 4>(a, groups, s);
+        case 83: return launch_wreg<1, 2>(a, groups, s);
+        case 90: return launch_wreg<2, 2, 1>(a, groups, s);      // timing ablations of 80
+        case 91: return launch_wreg<2, 2, 2>(a, groups, s);
+        case 92: return launch_wreg<2, 2, 3>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
         case 52: return launch_regw2_any(a, groups, s);
@@ -2388,6 +2401,61 @@ extern "C" int w2c_conv_igemm_bf16(const uint16_t* x, int M, int H, int W, int C
     if (rc != W2C_OK) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return launch_variant(pick_variant(a, groups), a, groups, s);
+}
+
+// [groups][Cout][9*Cin] (K = tap * Cin + c) -> fragment order of conv_wreg.inl:
+// [groups][Cout/32][chunk*9 + tap][k slice 0..3][half][channel % 32][8 elements]; one thread per 16 bytes
+__global__ void pack_wfrag_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin, long n16) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    // destination index -> (g, nb, cc, tap, kk, half, c32)
+    long r = i;
+    const int c32 = (int)(r & 31); r >>= 5;
+    const int half = (int)(r & 1); r >>= 1;
+    const int kk = (int)(r & 3); r >>= 2;
+    const int tap = (int)(r % 9); r /= 9;
+    const int nch = Cin >> 6;
+    const int cc = (int)(r % nch); r /= nch;
+    const int nbn = Cout >> 5;
+    const int nb = (int)(r % nbn);
+    const long g = r / nbn;
+    const long src = ((g * Cout + nb * 32 + c32) * 9 + tap) * (long)Cin + cc * 64 + kk * 16 + half * 8;    // elements
+    out[i] = w[src >> 3];
+}
+
+extern "C" int w2c_pack_wfrag_bf16(const uint16_t* w, uint16_t* wfrag, int groups, int Cout, int Cin, w2c_stream_t stream) {
+    if (!w || !wfrag || groups <= 0 || Cout <= 0 || Cin <= 0 || (Cout % 32) != 0 || (Cin % 64) != 0) return W2C_E_ARG;
+    w2c_clear_error();
+    const long n16 = (long)groups * Cout * 9 * Cin / 8;
+    hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint4*>(w), reinterpret_cast<uint4*>(wfrag), Cout, Cin, n16);
+    return w2c_launch_status();
+}
+
+// Which layers go to the weights-to-registers kernel, from the cfg-2 layer sweeps (profiles/r03_wreg_kernel.txt): the deep
+// layers (Cin >= 256: layer3, layer4, policy conv1 / conv2, decoder conv0) gain 8-30 %; layer2 (Cin = 128: 18 K-steps) does not.
+// A function of the layer geometry only.
+static int wreg_form(int H, int W, int Cin, int Cout) {
+    if (H <= 0 || W <= 0 || (H % 8) != 0 || (W % 16) != 0 || (Cin % 64) != 0 || (Cout % 64) != 0) return 0;
+    if (Cin < 256) return 0;
+    return 81;
+}
+extern "C" int w2c_conv3x3_wreg_supported(int H, int W, int Cin, int Cout) { return wreg_form(H, W, Cin, Cout) != 0; }
+
+extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                     const uint16_t* wfrag, int Cout, int groups,
+                                     const float* scale, const float* shift, const uint16_t* residual, int relu,
+                                     uint16_t* y, int y_cstride, long long y_group_stride, int form, w2c_stream_t stream) {
+    ConvArgs a;
+    // (the zero page is unused by this kernel: out-of-image halo pixels are out-of-range buffer offsets)
+    const int rc = fill_args(a, x, M, H, W, Cin, x_cstride, wfrag, Cout, 3, 1, groups, scale, shift, residual, relu, y, y_cstride, 0,
+                             /*zero_page=*/x, y_group_stride);
+    if (rc != W2C_OK) return rc;
+    if ((size_t)M * H * W * y_cstride * 2 >= (1ull << 31)) return W2C_E_ARG;      // 32-bit element offsets in the epilogue
+    if (form == 0) form = wreg_form(H, W, Cin, Cout);
+    if (form != 80 && form != 81 && form != 83) return W2C_E_ARG;
+    w2c_clear_error();
+    return launch_variant(form, a, groups, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,

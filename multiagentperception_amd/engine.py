@@ -35,6 +35,9 @@ def _fold_bn(bn, conv_bias=None):
     return scale, shift
 
 
+_USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
+
+
 def _pack_w(conv_weight):
     """[Cout, Cin, kh, kw] f32 -> [Cout, kh*kw*Cin] bf16 (tap-major, channel-minor K)."""
     w = conv_weight.detach().float()
@@ -75,8 +78,18 @@ class ConvPlan:
         self.w = torch.stack(ws, 0).contiguous()
         self.scale = torch.cat(scs).contiguous()
         self.shift = torch.cat(shs).contiguous()
+        # deep 3x3 / stride-1 layers also keep a fragment-ordered copy of their weights for the weights-to-registers kernel
+        # (w2c_conv3x3_wreg_bf16); whether a call uses it is the library's decision, from the layer geometry only
+        self.wfrag = None
+        if (_USE_WREG and self.ksize == 3 and self.stride == 1 and self.cin % 64 == 0 and self.cout % 64 == 0 and self.w.is_cuda
+                and ops.conv3x3_wreg_supported(8, 16, self.cin, self.cout)):
+            self.wfrag = ops.pack_wfrag_device(self.w, self.cin)
 
     def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None, out=None, out_ch_off=0):
+        if (self.wfrag is not None and not out_f32 and out_groups is None
+                and ops.conv3x3_wreg_supported(x.shape[1], x.shape[2], self.cin, self.cout)):
+            return ops.conv3x3_wreg(x, x_ch_off, self.cin, self.wfrag, self.cout, self.groups, self.scale, self.shift,
+                                    residual=residual, relu=self.relu, out=out, out_ch_off=out_ch_off)
         # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
                               self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,

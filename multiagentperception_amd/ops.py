@@ -225,6 +225,18 @@ def splitk_workspace(dev, nbytes):
     return ws
 
 
+def pack_wfrag(w_packed, cin):
+    """[G, Cout, 9*cin] bf16 weights (K = (tap, cin), the layout every other conv kernel reads) -> the MFMA A-fragment order of
+    the weights-to-registers 3x3 kernels (csrc/conv_wreg.inl): [G][Cout/32][chunk*9 + tap][k slice 0..3][half][channel % 32][8],
+    i.e. one contiguous 1 KB block per (32 channels, K-step, 16-deep k slice) in lane order.  Same bytes, permuted."""
+    G, cout, K = w_packed.shape
+    if K != 9 * cin or cin % 64 or cout % 32:
+        raise W2CError("pack_wfrag: needs a 3x3 conv with cin % 64 == 0 and cout % 32 == 0")
+    nch = cin // 64
+    v = w_packed.reshape(G, cout // 32, 32, 9, nch, 4, 2, 8)          # g, nb, c32, tap, cc, kk, half, e
+    return v.permute(0, 1, 4, 3, 5, 6, 2, 7).contiguous().reshape(G, cout, K)
+
+
 _MAX_X_BYTES = (1 << 31) - 1       # the conv kernels address x through a 32-bit buffer descriptor (include/w2c_hip.h)
 
 
@@ -324,6 +336,61 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
         nbytes = (M * H * W * cin * groups * 2 + M * Ho * Wo * cout * groups * (4 if out_f32 else 2)
                   + (M * Ho * Wo * cout * groups * 2 if residual is not None else 0) + groups * cout * ksize * ksize * cin * 2)
         timer.end(tok, dev, flops, (M * Ho * Wo, cin, cout, ksize, stride, groups), nbytes)
+    return out
+
+
+def pack_wfrag_device(w_packed, cin):
+    """w2c_pack_wfrag_bf16: the library's own (device-side) form of pack_wfrag."""
+    dev = _need_gpu(w_packed)
+    G, cout, K = w_packed.shape
+    if K != 9 * cin:
+        raise W2CError("pack_wfrag: needs 3x3 weights [G, Cout, 9*cin]")
+    out = torch.empty_like(w_packed)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_pack_wfrag_bf16(_p(w_packed), _p(out), G, cout, cin, _stream(dev)), "w2c_pack_wfrag_bf16")
+    return out
+
+
+def conv3x3_wreg_supported(H, W, cin, cout):
+    return bool(_native.lib().w2c_conv3x3_wreg_supported(int(H), int(W), int(cin), int(cout)))
+
+
+def conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, residual=None, relu=True, out=None, out_cstride=None,
+                 form=0, out_ch_off=0, _gstride=0):
+    """w2c_conv3x3_wreg_bf16: 3x3 / stride 1 / pad 1, bf16 NHWC in and out; `wfrag` from pack_wfrag_device.  Same tensor
+    conventions as conv_igemm (x_ch_off, out_ch_off, groups side by side unless _gstride)."""
+    dev = _need_gpu(x, wfrag, scale, shift, residual, out)
+    M, H, W, xcs = x.shape
+    if out_cstride is None:
+        out_cstride = out.shape[3] if out is not None else groups * cout
+    if out is None:
+        out = torch.empty((M, H, W, out_cstride), dtype=BF16, device=dev)
+    if tuple(out.shape) != (M, H, W, out_cstride) or out.dtype != BF16:
+        raise W2CError("conv3x3_wreg: bad out tensor")
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or out_ch_off):
+        raise W2CError("conv3x3_wreg: residual geometry must equal the output geometry")
+    if x_ch_off < 0 or x_ch_off + groups * cin > xcs or out_ch_off % 8 or out_ch_off + (1 if _gstride else groups) * cout > out_cstride:
+        raise W2CError("conv3x3_wreg: channel window outside the tensor")
+    per_img = max(H * W * xcs * 2, H * W * out_cstride * 2)
+    if M * per_img > _MAX_X_BYTES:
+        step = max(1, _MAX_X_BYTES // per_img)
+        for lo in range(0, M, step):
+            hi = min(M, lo + step)
+            conv3x3_wreg(x[lo:hi], x_ch_off, cin, wfrag, cout, groups, scale, shift, None if residual is None else residual[lo:hi],
+                         relu, out[lo:hi], out_cstride, form, out_ch_off, _gstride)
+        return out
+    timer = getattr(_tls, "conv_timer", None)
+    tok = timer.begin(dev) if timer is not None else None
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv3x3_wreg_bf16(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(wfrag), cout, groups,
+                                                  _p(scale), _p(shift), _p(residual), 1 if relu else 0,
+                                                  out.data_ptr() + 2 * out_ch_off, out_cstride, int(_gstride), int(form), _stream(dev)),
+              "w2c_conv3x3_wreg_bf16")
+    if timer is not None:
+        flops = 2.0 * M * H * W * cout * 9 * cin * groups
+        nbytes = (M * H * W * cin * groups * 2 + M * H * W * cout * groups * 2
+                  + (M * H * W * cout * groups * 2 if residual is not None else 0) + groups * cout * 9 * cin * 2)
+        timer.end(tok, dev, flops, (M * H * W, cin, cout, 3, 1, groups), nbytes)
     return out
 
 

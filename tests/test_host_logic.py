@@ -286,3 +286,16 @@ def test_loss_registry_mirrors_the_reference_and_cpu_tensors_use_torch():
     want = F.cross_entropy(x, t, ignore_index=250)
     assert torch.allclose(cross_entropy2d(input=x, target=t), want)
     assert float(fn(input=x, target=t)) > float(want)          # the mean of the 16 hardest pixels exceeds the mean of all
+
+
+def test_pack_wfrag_layout_is_the_mfma_a_fragment_order():
+    """ops.pack_wfrag (CPU-capable twin of w2c_pack_wfrag_bf16): block (g, nb, t = chunk*9 + tap, slice kk) holds, at lane
+    l = half*32 + c, the 8 weights W[nb*32 + c][tap][chunk*64 + kk*16 + half*8 .. +8] -- one MFMA 32x32x16 A fragment."""
+    import torch
+    from multiagentperception_amd import ops
+    G, cout, cin = 2, 64, 128
+    w = torch.arange(G * cout * 9 * cin, dtype=torch.float32).reshape(G, cout, 9 * cin)
+    f = ops.pack_wfrag(w, cin).reshape(G, cout // 32, 2 * 9, 4, 2, 32, 8)
+    for (g, nb, cc, tap, kk, half, c) in ((0, 0, 0, 0, 0, 0, 0), (1, 1, 1, 8, 3, 1, 31), (0, 1, 0, 4, 2, 0, 17), (1, 0, 1, 2, 1, 1, 5)):
+        k0 = tap * cin + cc * 64 + kk * 16 + half * 8
+        assert torch.equal(f[g, nb, cc * 9 + tap, kk, half, c], w[g, nb * 32 + c, k0:k0 + 8])

@@ -946,3 +946,95 @@ def test_conv_launch_spans_are_recorded_on_every_graph_replay():
         seen.append(int(timer.buf[2, 0]))
         assert torch.equal(y, plain)
     assert seen[1] > seen[0]                                     # a fresh stamp per replay
+
+
+# ---- weights-to-registers 3x3 kernel (csrc/conv_wreg.inl) through w2c_pack_wfrag_bf16 / w2c_conv3x3_wreg_bf16 ----
+WREG_CASES = [
+    # form, M, H, W, Cin, Cout, groups, residual, relu, x channel pad, y channel pad
+    (80, 2, 8, 16, 64, 128, 1, True, True, 0, 0),          # one tile per image: halo on every side is out of the image
+    (80, 3, 16, 32, 128, 128, 2, True, True, 8, 16),       # 2 chunks, 2 groups, wider channel strides
+    (80, 1, 24, 16, 256, 256, 1, False, False, 0, 0),      # 4 chunks, 2 channel tiles, no ReLU (negative outputs survive)
+    (81, 2, 8, 16, 64, 64, 1, True, True, 0, 0),           # K split 4: one chunk (odd slice count: parity tail)
+    (81, 3, 16, 16, 192, 64, 2, False, True, 0, 8),        # 3 chunks (odd), 2 groups
+    (81, 1, 16, 48, 512, 128, 1, True, True, 0, 0),        # 8 chunks, interior tiles with real halos left and right
+    (83, 2, 16, 16, 128, 64, 2, True, False, 8, 0),
+    (0, 2, 16, 16, 256, 128, 1, True, True, 0, 0),         # the library's own choice of form
+]
+
+
+def _wreg_setup(case, seed):
+    form, M, H, W, cin, cout, G, use_res, relu, xpad, ypad = case
+    gen = torch.Generator().manual_seed(seed)
+    xs = [_rand(gen, M, cin, H, W) for _ in range(G)]
+    ws = [_rand(gen, cout, cin, 3, 3, scale=(2.0 / (cin * 9)) ** 0.5) for _ in range(G)]
+    scale = torch.rand(G * cout, generator=gen) + 0.5
+    shift = torch.randn(G * cout, generator=gen) * 0.1
+    ress = [_rand(gen, M, cout, H, W) for _ in range(G)] if use_res else None
+    x_dev = torch.zeros(M, H, W, G * cin + xpad, dtype=BF16)
+    for g in range(G):
+        x_dev[..., g * cin:(g + 1) * cin] = xs[g].permute(0, 2, 3, 1).to(BF16)
+    w_dev = torch.stack([w.permute(0, 2, 3, 1).reshape(cout, -1).to(BF16) for w in ws], 0).contiguous().to(_dev())
+    res_dev = None
+    if use_res:
+        res_dev = torch.zeros(M, H, W, G * cout + ypad, dtype=BF16)
+        for g in range(G):
+            res_dev[..., g * cout:(g + 1) * cout] = ress[g].permute(0, 2, 3, 1).to(BF16)
+        res_dev = res_dev.to(_dev())
+    return xs, ws, scale, shift, ress, x_dev.to(_dev()), w_dev, res_dev
+
+
+def test_pack_wfrag_device_matches_the_documented_permutation():
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    for G, cout, cin in ((1, 32, 64), (2, 96, 192), (1, 128, 256)):
+        w = torch.randn(G, cout, 9 * cin, generator=gen).to(BF16).to(_dev())
+        got = ops.pack_wfrag_device(w, cin)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ops.pack_wfrag(w, cin))
+
+
+@pytest.mark.parametrize("case", WREG_CASES, ids=[str(c) for c in WREG_CASES])
+def test_conv3x3_wreg_matches_fp32_conv(case):
+    from multiagentperception_amd import ops
+    form, M, H, W, cin, cout, G, use_res, relu, xpad, ypad = case
+    xs, ws, scale, shift, ress, x_dev, w_dev, res_dev = _wreg_setup(case, hash(case) & 0xFFFF)
+    wfrag = ops.pack_wfrag_device(w_dev, cin)
+    out = torch.full((M, H, W, G * cout + ypad), 7.0, dtype=BF16, device=_dev())
+    y = ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, G, scale.to(_dev()), shift.to(_dev()), residual=res_dev, relu=relu, out=out,
+                         form=form)
+    torch.cuda.synchronize()
+    for g in range(G):
+        ref = F.conv2d(xs[g], ws[g], None, stride=1, padding=1)
+        ref = ref * scale[g * cout:(g + 1) * cout].view(1, -1, 1, 1) + shift[g * cout:(g + 1) * cout].view(1, -1, 1, 1)
+        if use_res:
+            ref = ref + ress[g]
+        if relu:
+            ref = F.relu(ref)
+        # bf16 out: accumulation order + one bf16 rounding of the result (same bound as test_conv_igemm_matches_fp32_conv)
+        np.testing.assert_allclose(_to_nchw(y, g * cout, cout).numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
+    if ypad:
+        assert bool((y[..., G * cout:] == 7.0).all()), "channels outside the written window were touched"
+    # and against the ring kernels on the same operands: at most one bf16 ulp apart (different K summation order)
+    y0 = ops.conv_igemm(x_dev, 0, cin, w_dev, cout, 3, 1, G, scale.to(_dev()), shift.to(_dev()),
+                        residual=None if res_dev is None else res_dev[..., :G * cout].contiguous(), relu=relu)
+    d = (y[..., :G * cout].float() - y0.float()).abs()
+    assert float((d / (y0.float().abs() + 1.0)).max()) <= 2 ** -7
+
+
+def test_conv3x3_wreg_is_independent_of_the_image_count_and_repeatable():
+    """one workgroup per 8 x 16-pixel tile, fixed summation order: image i of a batch equals the same image run alone, bit for
+    bit; 40 repeats of one launch are identical (race screen for the patch ring / exchange area hand-offs)."""
+    from multiagentperception_amd import ops
+    for form in (80, 81, 83):
+        case = (form, 5, 16, 32, 256, 128, 2, True, True, 0, 0)
+        xs, ws, scale, shift, ress, x_dev, w_dev, res_dev = _wreg_setup(case, 77 + form)
+        wfrag = ops.pack_wfrag_device(w_dev, 256)
+        sc, sh = scale.to(_dev()), shift.to(_dev())
+        full = ops.conv3x3_wreg(x_dev, 0, 256, wfrag, 128, 2, sc, sh, residual=res_dev, form=form).clone()
+        for i in (0, 3, 4):
+            one = ops.conv3x3_wreg(x_dev[i:i + 1].contiguous(), 0, 256, wfrag, 128, 2, sc, sh,
+                                   residual=res_dev[i:i + 1].contiguous(), form=form)
+            assert torch.equal(one[0], full[i])
+        for _ in range(40):
+            again = ops.conv3x3_wreg(x_dev, 0, 256, wfrag, 128, 2, sc, sh, residual=res_dev, form=form)
+            assert torch.equal(again, full)

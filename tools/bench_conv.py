@@ -26,12 +26,23 @@ LAYERS = [
     ("pol4 256->256 @8", 20, 8, 8, 256, 256, 3, 1, 1, False),
     ("pol5 256->256 s2 @8", 20, 8, 8, 256, 256, 3, 2, 1, False),
     ("dec1 256->32 @16 f32", 20, 16, 16, 256, 32, 3, 1, 1, False),
+    # single-trunk (one group) forms of the chain launches, and 8x deeper-K forms (main-loop ceiling)
+    ("c2 128->128 @64 g1 res", 20, 64, 64, 128, 128, 3, 1, 1, True),
+    ("c3 256->256 @32 g1 res", 20, 32, 32, 256, 256, 3, 1, 1, True),
+    ("c4 512->512 @16 g1 res", 20, 16, 16, 512, 512, 3, 1, 1, True),
+    ("k2 1024->128 @64 g1", 20, 64, 64, 1024, 128, 3, 1, 1, False),
+    ("k3 2048->256 @32 g1", 20, 32, 32, 2048, 256, 3, 1, 1, False),
+    ("q2 1024->128 @64 M16", 16, 64, 64, 1024, 128, 3, 1, 1, False),
+    ("q3 2048->256 @32 M32", 32, 32, 32, 2048, 256, 3, 1, 1, False),
 ]
 VALID = {  # variant -> (BM, BN, BK)
     0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
     30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64),
+    72: (256, 128, 64), 73: (128, 128, 64), 74: (128, 128, 64),
+    80: (128, 128, 64), 81: (128, 64, 64), 82: (128, 128, 64), 83: (128, 64, 64), 84: (128, 256, 64),
+    86: (128, 256, 64), 87: (128, 256, 64), 88: (128, 256, 64), 90: (128, 128, 64), 91: (128, 128, 64), 92: (128, 128, 64),
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 72: (16, 16), 73: (8, 16), 74: (8, 16), 80: (8, 16), 81: (8, 16), 82: (8, 16), 83: (8, 16), 84: (8, 16), 86: (8, 16), 87: (8, 16), 88: (8, 16), 90: (8, 16), 91: (8, 16), 92: (8, 16)}
 
 
 def main():
@@ -59,8 +70,14 @@ def main():
             if (v in (38, 39, 50) and cin != 64) or (v == 50 and cout != 64) or (v == 51 and (cin != 128 or cout != 128)) or cout % bn or cin % bk or (v in PATCH_GEOM and (ks != 3 or st != 1 or H % PATCH_GEOM[v][0] or W % PATCH_GEOM[v][1])):
                 cells.append("%16s" % "-")
                 continue
+            wv = w
+            if v >= 80:
+                if f32:
+                    cells.append("%16s" % "-")
+                    continue
+                wv = ops.pack_wfrag(w, cin)
             try:
-                y = ops.conv_igemm(x, 0, cin, w, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v)
+                y = ops.conv_igemm(x, 0, cin, wv, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v)
                 torch.cuda.synchronize()
             except Exception as e:  # noqa
                 cells.append("%16s" % ("ERR"))
@@ -76,15 +93,30 @@ def main():
                     d = float((ref.float() - y.float()).abs().max())
                     okm = "~" if d <= 0.0626 else "!%.2g!" % d      # different K order: <= 1 bf16 ulp at |y| < 8
             for _ in range(3):
-                ops.conv_igemm(x, 0, cin, w, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v, out=y)
+                ops.conv_igemm(x, 0, cin, wv, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v, out=y)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             n = iters
-            e0.record()
-            for _ in range(n):
-                ops.conv_igemm(x, 0, cin, w, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v, out=y)
-            e1.record()
-            torch.cuda.synchronize()
+            if os.environ.get("W2C_GRAPH", "1") != "0":      # graph replay: the Python launch path (~30 us per call) is out of the timing
+                gr = torch.cuda.CUDAGraph()
+                st_ = torch.cuda.Stream()
+                st_.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st_):
+                    with torch.cuda.graph(gr, stream=st_):
+                        for _ in range(n):
+                            ops.conv_igemm(x, 0, cin, wv, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v, out=y)
+                    gr.replay()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    gr.replay()
+                    e1.record()
+                torch.cuda.synchronize()
+            else:
+                e0.record()
+                for _ in range(n):
+                    ops.conv_igemm(x, 0, cin, wv, cout, ks, st, G, sc, sh, residual=r, relu=True, out_f32=f32, variant=v, out=y)
+                e1.record()
+                torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1000.0 / n
             cells.append("%16s" % ("%s%.1fus %4.0fTF" % (okm, us, flops / us / 1e6)))
         print("%-26s" % name + "".join(cells))
