@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -2263,6 +2263,8 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 80: return launch_wreg<2, 2>(a, groups, s);
         case 81: return launch_wreg<1, 4>(a, groups, s);
         case 83: return launch_wreg<1, 2>(a, groups, s);
+        case 93: return launch_wreg<1, 4, 0, 4>(a, groups, s);   // 81 with the weights 4 / 2 K-steps ahead instead of 8
+        case 94: return launch_wreg<1, 4, 0, 2>(a, groups, s);
         case 90: return launch_wreg<2, 2, 1>(a, groups, s);      // timing ablations of 80
         case 91: return launch_wreg<2, 2, 2>(a, groups, s);
         case 92: return launch_wreg<2, 2, 3>(a, groups, s);
@@ -2437,8 +2439,12 @@ extern "C" int w2c_pack_wfrag_bf16(const uint16_t* w, uint16_t* wfrag, int group
 // A function of the layer geometry only.
 static int wreg_form(int H, int W, int Cin, int Cout) {
     if (H <= 0 || W <= 0 || (H % 8) != 0 || (W % 16) != 0 || (Cin % 64) != 0 || (Cout % 64) != 0) return 0;
-    if (Cin < 256) return 0;
-    return 81;
+    const int mincin = w2c_option(W2C_OPT_WREG_MINCIN);
+    if (mincin <= 0 || Cin < mincin) return 0;
+    const int forced = w2c_option(W2C_OPT_WREG_FORM);
+    if (forced == 80 && (Cout % 128) != 0) return 93;
+    if (forced) return forced;
+    return 93;                                       // 1 channel block x 4 K groups, weights 4 K-steps ahead
 }
 extern "C" int w2c_conv3x3_wreg_supported(int H, int W, int Cin, int Cout) { return wreg_form(H, W, Cin, Cout) != 0; }
 
@@ -2453,7 +2459,7 @@ extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int
     if (rc != W2C_OK) return rc;
     if ((size_t)M * H * W * y_cstride * 2 >= (1ull << 31)) return W2C_E_ARG;      // 32-bit element offsets in the epilogue
     if (form == 0) form = wreg_form(H, W, Cin, Cout);
-    if (form != 80 && form != 81 && form != 83) return W2C_E_ARG;
+    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94) return W2C_E_ARG;
     w2c_clear_error();
     return launch_variant(form, a, groups, reinterpret_cast<hipStream_t>(stream));
 }

@@ -25,7 +25,7 @@
 //     before the exchange) + ReLU, bf16 pack, v_permlane32_swap pairs the half-waves' channel quads into 16-byte stores.
 // LDS: 72 KB of patch buffers -> two workgroups per CU; 128 AGPRs + <= 128 VGPRs -> two waves per SIMD.
 // The K order differs from the ring kernels' (partial sums per K group): results agree to f32 rounding, not bit for bit.
-template <int NN, int KS, int ABL = 0>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
+template <int NN, int KS, int ABL = 0, int DW = 8>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
 __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PW = 18, NP = 180, NPIECE = 23;  // patch: 10 x 18 pixels, 128 B each, DMA'd in 1 KB pieces of 8 pixels
@@ -34,7 +34,10 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     constexpr int PATCH_STRIDE = P_INSTR * NW * 1024;   // every wave issues P_INSTR pieces; those past the patch (and the last piece's
                                                         // 4 dead pixels) are all-out-of-range loads that write zeros into the pad
     constexpr int KK = 4 / KS;                     // k slices (16 deep) per K-step per wave
-    constexpr int D = 2, R = 3;                    // weights are loaded D K-steps ahead into a ring of R register sets (R divides 9)
+    // weights are loaded D K-steps ahead into a ring of R register sets (R divides 9, D < R).  A K-step is 8 KK MFMAs = 256 KK cycles
+    // of matrix pipe per wave: with one slice per step (KS = 4) two steps ahead is only ~0.5-1k cycles -- less than an L2 round
+    // trip under load -- so that form runs a 9-deep ring (72 VGPRs), DW steps ahead
+    constexpr int R = (KK == 1 && DW > 2) ? 9 : 3, D = KK == 1 ? DW : 2;
     constexpr int NB_SYNC = 16 * KK > 56 ? 56 : 16 * KK;   // weight loads a wave issues between a patch and the chunk sync that needs it (>=)
     static_assert(KS == 1 || KS == 2 || KS == 4, "K split");
     // one dummy "a" operand makes the backend pick the AGPR form of every builtin MFMA here (accumulators in AGPRs)
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
 #endif
 }
 
-template <int NN, int KS, int ABL = 0>
+template <int NN, int KS, int ABL = 0, int DW = 8>
 int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
     if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % (NN * 64) != 0 || a.H % 8 != 0 || a.W % 16 != 0 || a.y_f32 || a.y8 ||
         !a.y || a.ws)
@@ -356,10 +359,10 @@ int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
     a.xcd2d = 0;
-    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
     return w2c_launch_status();
 }

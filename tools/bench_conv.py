@@ -40,9 +40,9 @@ VALID = {  # variant -> (BM, BN, BK)
     30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64),
     72: (256, 128, 64), 73: (128, 128, 64), 74: (128, 128, 64),
     80: (128, 128, 64), 81: (128, 64, 64), 82: (128, 128, 64), 83: (128, 64, 64), 84: (128, 256, 64),
-    86: (128, 256, 64), 87: (128, 256, 64), 88: (128, 256, 64), 90: (128, 128, 64), 91: (128, 128, 64), 92: (128, 128, 64),
+    93: (128, 64, 64), 94: (128, 64, 64), 90: (128, 128, 64), 91: (128, 128, 64), 92: (128, 128, 64),
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 72: (16, 16), 73: (8, 16), 74: (8, 16), 80: (8, 16), 81: (8, 16), 82: (8, 16), 83: (8, 16), 84: (8, 16), 86: (8, 16), 87: (8, 16), 88: (8, 16), 90: (8, 16), 91: (8, 16), 92: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 72: (16, 16), 73: (8, 16), 74: (8, 16), 80: (8, 16), 81: (8, 16), 82: (8, 16), 83: (8, 16), 84: (8, 16), 93: (8, 16), 94: (8, 16), 90: (8, 16), 91: (8, 16), 92: (8, 16)}
 
 
 def main():
