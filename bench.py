@@ -156,12 +156,13 @@ def scene_accuracy(arch, n_agents, batch, size, has_query, dev, build_cfg_fn, se
 
 # ---- HBM traffic of the dominant kernel family from rocprofv3 PMC passes (this script profiles itself) --------------
 def _is_conv_kernel(name):
-    return ("conv_igemm_kernel" in name or "conv3x3_" in name or "splitk_finish_kernel" in name or "conv_mx" in name)
+    return ("conv_igemm_kernel" in name or "conv3x3" in name or "splitk_finish_kernel" in name or "conv_inwg_splitk_kernel" in name
+            or "conv_mx" in name)
 
 
 def _short_kernel(name):
     import re
-    m = re.search(r"((?:conv_igemm_kernel|conv3x3_patch_kernel|conv3x3_c64_regw_kernel|splitk_finish_kernel)(?:<[^>]*>)?)", name)
+    m = re.search(r"((?:conv_igemm_kernel|conv3x3_patch_kernel|conv3x3s2_patch_kernel|conv3x3_wreg_kernel|conv3x3_c64_regw_kernel|conv_inwg_splitk_kernel|splitk_finish_kernel)(?:<[^>]*>)?)", name)
     return m.group(1) if m else name[:64]
 
 

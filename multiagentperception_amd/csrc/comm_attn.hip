@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const void* __restrict__ xv
 // L2-resident: M*K*2 bytes), MR rows accumulate per pass, then wave shuffle + cross-wave LDS
 // reduction.  The one-wave-per-output form above serialises K/256 dependent iterations per row and
 // ran 76 us for M=20, K=4096, O=256 (r01_a profile); this form is bound by the 4 MB weight read.
+// MR = 20 rows per pass: cfg 2's 20 agent-images take ONE pass over the weight row (MR = 8 took three).
 template <int MR, bool XBF16>
 __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restrict__ xv, int x_stride, int M, int K,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restric
         float acc[MR];
 #pragma unroll
         for (int r = 0; r < MR; ++r) acc[r] = 0.f;
-        for (int k = tid * 4; k < K; k += 1024) {
+#pragma unroll 4
+        for (int k = tid * 4; k < K; k += 1024) {      // (unrolled: every load of up to 4 K-slices in flight -- the kernel is load latency)
             const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wrow + k);
 #pragma unroll
             for (int r = 0; r < MR; ++r) {
@@ -153,6 +155,13 @@ __device__ __forceinline__ void head_tail_body(const float* __restrict__ h0, int
         if (part < parts) {
             const int kn = (K1 - part + parts - 1) / parts;           // this partition's k count: k = part + i*parts
             int i = 0;
+            for (; i + 31 < kn; i += 32) {                             // 32 loads in flight (same summation order as the 16-wide step)
+                float wv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) wv[u] = w1t[(size_t)(part + (i + u) * parts) * H1 + j];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) a[u & 3] = fmaf(wv[u], s_h0[part + (i + u) * parts], a[u & 3]);
+            }
             for (; i + 15 < kn; i += 16) {
                 float wv[16];
 #pragma unroll
@@ -176,6 +185,13 @@ __device__ __forceinline__ void head_tail_body(const float* __restrict__ h0, int
     if (o < O) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         int k = 0;
+        for (; k + 31 < H1; k += 32) {
+            float wv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) wv[u] = w2t[(size_t)(k + u) * O + o];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) a[u & 3] = fmaf(wv[u], s_h1[k + u], a[u & 3]);
+        }
         for (; k + 15 < H1; k += 16) {
             float wv[16];
 #pragma unroll
@@ -345,6 +361,46 @@ __global__ __launch_bounds__(256) void fuse_kernel(const uint16_t* __restrict__ 
     __syncthreads();
     const int CG = C >> 3;
     const int total = hw * CG;
+    if (N <= 8 && q_n <= 8) {
+        // small graphs (cfg 2: 5 x 5): every key's 16 bytes are loaded ONCE, all together, and reused by all queries -- the general
+        // loop below re-reads them per query behind a store (q_n dependent load rounds).  Same fmaf order per output: same bits.
+        for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+            const int px = id / CG, cg = id - px * CG;
+            uint4 vk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                vk[k] = k < N ? *reinterpret_cast<const uint4*>(v + ((size_t)(k * B + b) * hw + px) * vcs + cg * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int ql = 0; ql < 8; ++ql) {
+                if (ql >= q_n) break;
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k >= N) break;
+                    const float c = cs[k * q_n + ql];
+                    if (c == 0.f) continue;
+                    const uint32_t wv[4] = {vk[k].x, vk[k].y, vk[k].z, vk[k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] = fmaf(c, bf16_to_f32((uint16_t)(wv[e] & 0xFFFFu)), acc[2 * e]);
+                        acc[2 * e + 1] = fmaf(c, bf16_to_f32((uint16_t)(wv[e] >> 16)), acc[2 * e + 1]);
+                    }
+                }
+                uint4 o;
+                o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+                o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+                uint16_t* orow = out + ((size_t)(ql * B + b) * hw + px) * ocs;
+                *reinterpret_cast<uint4*>(orow + cg * 8) = o;
+                if (append_own) {
+                    const uint4 own = *reinterpret_cast<const uint4*>(v + ((size_t)((q_lo + ql) * B + b) * hw + px) * vcs + cg * 8);
+                    *reinterpret_cast<uint4*>(orow + C + cg * 8) = own;
+                }
+            }
+        }
+        return;
+    }
     for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
         const int px = id / CG, cg = id - px * CG;
         for (int ql = 0; ql < q_n; ++ql) {
@@ -454,9 +510,9 @@ extern "C" int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (K >= 1024) {
         if (x_is_bf16)
-            hipLaunchKernelGGL((linear_widek_kernel<8, true>), dim3(O), dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+            hipLaunchKernelGGL((linear_widek_kernel<20, true>), dim3(O), dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
         else
-            hipLaunchKernelGGL((linear_widek_kernel<8, false>), dim3(O), dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
+            hipLaunchKernelGGL((linear_widek_kernel<20, false>), dim3(O), dim3(256), 0, s, x, x_stride, M, K, w, b, O, relu, y);
         return w2c_launch_status();
     }
     dim3 grid((O + 3) / 4);
