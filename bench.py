@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--mode", default="softmax", choices=["softmax", "argmax_test", "activated"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--inflight", type=int, default=3, help="side figure: throughput with this many forwards in flight (1 = skip)")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3, MX-scaled MFMA) trunk convs")
     ap.add_argument("--bf16", action="store_true", help="force the bf16 trunk (cfg5 defaults to fp8)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -533,6 +534,39 @@ def main():
                                         ms_per_step=round(1e3 * el / args.steps, 4),
                                         labels_equal_argmax_of_headline_logits=bool(torch.equal(lab[0].long(), out[0].max(1)[1])),
                                         confusion_equals_host_bincount=bool((hist.cpu().numpy() == want * args.steps).all()))
+
+    # ---- throughput with several forwards in flight (a serving loop), reported beside the headline, never as `value` ---
+    # F engines with their own activation buffers and captured graphs, one stream each, launched round-robin: the latency-bound tail of
+    # one forward (heads, graph, decoder: a nearly idle chip) runs beside the next forward's trunk.  The headline keeps one forward
+    # at a time (its ms_per_step is a latency); tools/pipeline2.py is the same loop stand-alone.
+    if world == 1 and not args.force_sharded and model.use_hip_graph and args.inflight > 1:
+        F = args.inflight
+        extra = []
+        for _ in range(F - 1):
+            m2 = get_model(build_cfg(arch, N, S, preset["query"]), 11)
+            filler.apply_to_module(m2)                  # deterministic filler: the same weights in every copy
+            m2 = m2.to(dev).eval()
+            m2.use_hip_graph = True
+            _apply_precision(m2, args)
+            extra.append(m2)
+        models = [model] + extra
+        streams = [torch.cuda.Stream(dev) for _ in range(F)]
+        outs = [None] * F
+        for i in range(3 * F):
+            with torch.cuda.stream(streams[i % F]):
+                outs[i % F] = models[i % F](x, training=False, MO_flag=True, inference=args.mode)
+        torch.cuda.synchronize(dev)
+        n_it = max(args.steps, 2 * F)
+        t0 = time.perf_counter()
+        for i in range(n_it):
+            with torch.cuda.stream(streams[i % F]):
+                outs[i % F] = models[i % F](x, training=False, MO_flag=True, inference=args.mode)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        result["forwards_in_flight"] = dict(forwards=F, value=round(images_per_step * n_it / el, 2), unit="agent-images/s",
+                                            ms_per_forward=round(1e3 * el / n_it, 4), forwards_timed=n_it,
+                                            outputs_equal_headline=bool(all(torch.equal(o[0], out[0]) for o in outs)))
+        del models, extra, outs
 
     # ---- HBM traffic of the conv family from PMC counters (N=1, rank 0) ---------------------------
     if rank == 0 and world == 1 and not args.no_pmc:

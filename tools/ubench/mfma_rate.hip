@@ -8,9 +8,20 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-template <int MODE>
+// RND: operands are pseudo-random bf16 values in +-[0.5, 1) (different in every lane and register) instead of the constant 1.0 --
+// the MFMA issue rate in CYCLES is the same, the clock the chip holds under the load is not (power): this is the ceiling a kernel
+// working on real data can reach.
+__device__ inline unsigned rnd_bf16x2(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return (x & 0x807F807Fu) | 0x3F003F00u;
+}
+template <int MODE, bool RND = false>
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, int iters) {
     u32x4_t a0 = {0x3f803f80u + threadIdx.x, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, a1 = a0, b0 = a0, b1 = a0;
+    if (RND) {
+        const unsigned h = (blockIdx.x * 256 + threadIdx.x) * 16;
+        for (int i = 0; i < 4; ++i) { a0[i] = rnd_bf16x2(h + i); a1[i] = rnd_bf16x2(h + 4 + i); b0[i] = rnd_bf16x2(h + 8 + i); b1[i] = rnd_bf16x2(h + 12 + i); }
+    }
     f32x16_t c0, c1, c2, c3;
     for (int i = 0; i < 16; ++i) { c0[i] = 0; c1[i] = 0; c2[i] = 0; c3[i] = 0; }
     asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
@@ -71,15 +82,15 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
     if (threadIdx.x == 0) cyc[blockIdx.x] = (unsigned long long)(t1 - t0);
 }
 
-template <int MODE>
+template <int MODE, bool RND = false>
 void run(const char* name, int nmfma_per_u) {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
     const int iters = 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE><<<256, 256>>>(out, cyc, 10);
+    k<MODE, RND><<<256, 256>>>(out, cyc, 10);
     hipEventRecord(e0);
-    k<MODE><<<256, 256>>>(out, cyc, iters);
+    k<MODE, RND><<<256, 256>>>(out, cyc, iters);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[256]; hipMemcpy(h, cyc, 256 * 8, hipMemcpyDeviceToHost);
@@ -156,6 +167,9 @@ int main() {
     run<4>("2 chains, runs of 4 back to back", 8);
     run<5>("2 chains alternating, everything in VGPRs", 4);
     run<6>("16x16x32, 4 chains (VGPR)", 4);
+    run<2, true>("4 chains round-robin, RANDOM operands", 4);
+    run<0, true>("1 chain, RANDOM operands", 4);
+    run<2>("4 chains round-robin, constant operands (again)", 4);
     runl<0>("LDS-fed, 2 chains, 1 ds_read_b128 per 2 MFMAs", 64);
     runl<1>("LDS-fed, same + s_nop 1", 64);
     runl<2>("LDS-fed, 4 chains, 1 ds_read_b128 per 4 MFMAs", 128);
