@@ -556,7 +556,7 @@ def main():
             with torch.cuda.stream(streams[i % F]):
                 outs[i % F] = models[i % F](x, training=False, MO_flag=True, inference=args.mode)
         torch.cuda.synchronize(dev)
-        n_it = max(args.steps, 2 * F)
+        n_it = max(3 * args.steps, 6 * F)          # long enough that the first / last forwards' solo phases do not weigh
         t0 = time.perf_counter()
         for i in range(n_it):
             with torch.cuda.stream(streams[i % F]):

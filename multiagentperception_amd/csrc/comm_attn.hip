@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const void* __restrict__ xv
 // L2-resident: M*K*2 bytes), MR rows accumulate per pass, then wave shuffle + cross-wave LDS
 // reduction.  The one-wave-per-output form above serialises K/256 dependent iterations per row and
 // ran 76 us for M=20, K=4096, O=256 (r01_a profile); this form is bound by the 4 MB weight read.
-// MR = 20 rows per pass: cfg 2's 20 agent-images take ONE pass over the weight row (MR = 8 took three).
+// MR = 20 rows per pass: cfg 2's 20 agent-images take ONE pass over the weight row (MR = 8 took three: 16.3 -> 14.7 us under graph replay, tools/bench_linear.py; the rest is the 20 wave reductions).
 template <int MR, bool XBF16>
 __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restrict__ xv, int x_stride, int M, int K,
                                                            const float* __restrict__ w, const float* __restrict__ bias,

@@ -52,8 +52,22 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     dbg_stamp(p, 0);
     const int tiles_x = p.W >> 4, tiles_y = p.H >> 3;
     const int g = blockIdx.y;
-    const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
-    const int tsp = tile / p.ntn, tn = tile - tsp * p.ntn;
+    int tsp, tn;
+    if (p.xcd2d) {
+        // weight-heavy layers (layer4: 4.7 MB of weights per conv against 4 MB of L2 per XCD; every wave streams its weights from
+        // L2): XCD x (= block id mod 8) owns one half of the pixel tiles and one quarter of the channel tiles -- 1.2 MB of weights +
+        // 2.6 MB of input per XCD instead of all the weights through every L2.  Fabric reads per layer4 launch 64 -> ~36 MB (PMC);
+        // time-neutral (the Infinity Cache holds everything).  Placement only: the result does not depend on it.
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int qn = p.ntn >> 2, hm = p.ntm >> 1;
+        const int tm_l = loc / qn;
+        tn = (xcd >> 1) * qn + (loc - tm_l * qn);
+        tsp = (xcd & 1) * hm + tm_l;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
+        tsp = tile / p.ntn;
+        tn = tile - tsp * p.ntn;
+    }
     const int txi = tsp % tiles_x, tyi = (tsp / tiles_x) % tiles_y, img = tsp / (tiles_x * tiles_y);
     const int y0 = tyi * 8, x0 = txi * 16;
     const int n0 = tn * (NN * 64) + nw * 64;        // this wave's first output channel inside the group
@@ -362,7 +376,9 @@ int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask |= 1ull << (dev & 63);
     }
-    a.xcd2d = 0;
+    const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);
+    const long wbytes = (long)a.Cout * 9 * a.Cin * 2;
+    a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20))) && !(a.ntm & 1) && !(a.ntn & 3);
     hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
     return w2c_launch_status();
 }

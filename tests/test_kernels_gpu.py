@@ -959,6 +959,8 @@ WREG_CASES = [
     (81, 1, 16, 48, 512, 128, 1, True, True, 0, 0),        # 8 chunks, interior tiles with real halos left and right
     (83, 2, 16, 16, 128, 64, 2, True, False, 8, 0),
     (0, 2, 16, 16, 256, 128, 1, True, True, 0, 0),         # the library's own choice of form
+    (93, 2, 16, 32, 512, 256, 1, True, True, 0, 0),        # weight-heavy: XCD-aware tile placement (4 channel tiles, 8 pixel tiles)
+    (94, 1, 8, 32, 128, 64, 1, False, True, 0, 0),
 ]
 
 
@@ -1038,3 +1040,16 @@ def test_conv3x3_wreg_is_independent_of_the_image_count_and_repeatable():
         for _ in range(40):
             again = ops.conv3x3_wreg(x_dev, 0, 256, wfrag, 128, 2, sc, sh, residual=res_dev, form=form)
             assert torch.equal(again, full)
+
+
+def test_conv3x3_wreg_xcd_placement_leaves_results_bit_identical(lib_option):
+    """W2C_XCD2D only changes which workgroup computes which tile"""
+    from multiagentperception_amd import ops
+    case = (93, 4, 16, 32, 512, 512, 1, True, True, 0, 0)
+    xs, ws, scale, shift, ress, x_dev, w_dev, res_dev = _wreg_setup(case, 31)
+    wfrag = ops.pack_wfrag_device(w_dev, 512)
+    outs = []
+    for mode in (0, 1, 2):
+        lib_option("W2C_XCD2D", mode)
+        outs.append(ops.conv3x3_wreg(x_dev, 0, 512, wfrag, 512, 1, scale.to(_dev()), shift.to(_dev()), residual=res_dev, form=93).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
