@@ -2255,19 +2255,15 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 36: return launch_patch<8, 16, 64, 4, 2, 3>(a, groups, s);      // 8 waves, 64 channels, 3-deep weight ring
         // Cin == 64 (one channel chunk): a single patch buffer -> ~39 KB of LDS -> four workgroups per CU
         case 38: return launch_patch<8, 16, 64, 2, 2, 2, 1>(a, groups, s);
-        // round-3 experiment: 128-pixel x 64-channel WAVE tiles (6 ds_read_b128 per 8 MFMAs instead of 4 per 4 / 2 per 1)
-        case 72: return launch_patch<16, 16, 128, 2, 2, 3>(a, groups, s);    // 4 waves, 256 px x 128 ch, one workgroup per CU
-        case 73: return launch_patch<8, 16, 128, 1, 2, 2>(a, groups, s);     // 2 waves, 128 px x 128 ch, two workgroups per CU
-        case 74: return launch_patch<8, 16, 128, 1, 2, 3>(a, groups, s);     // 2 waves, 3-deep ring (one workgroup per CU)
-        // weights-to-registers kernels (conv_wreg.inl; `w` must be in w2c_pack_wfrag order): NN channel blocks x KS K groups
+        // (round-3 experiment, removed: this kernel with 128-pixel x 64-channel WAVE tiles -- 4 waves on 16 x 16 x 128 / 2 waves on
+        //  8 x 16 x 128, one wave per SIMD -- 707-710 TFLOP/s on 8x deeper K against 906-991 / 792-871 for 36 / 30: the tile shape
+        //  alone buys nothing while the reads and the MFMAs of a step run one after the other; profiles/r03_wreg_kernel.txt section 1)
+        // weights-to-registers kernels (conv_wreg.inl; `w` must be in w2c_pack_wfrag_bf16 order): NN channel blocks x KS K groups
         case 80: return launch_wreg<2, 2>(a, groups, s);
         case 81: return launch_wreg<1, 4>(a, groups, s);
         case 83: return launch_wreg<1, 2>(a, groups, s);
         case 93: return launch_wreg<1, 4, 0, 4>(a, groups, s);   // 81 with the weights 4 / 2 K-steps ahead instead of 8
         case 94: return launch_wreg<1, 4, 0, 2>(a, groups, s);
-        case 90: return launch_wreg<2, 2, 1>(a, groups, s);      // timing ablations of 80
-        case 91: return launch_wreg<2, 2, 2>(a, groups, s);
-        case 92: return launch_wreg<2, 2, 3>(a, groups, s);
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
         case 52: return launch_regw2_any(a, groups, s);

@@ -38,11 +38,9 @@ LAYERS = [
 VALID = {  # variant -> (BM, BN, BK)
     0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
     30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64),
-    72: (256, 128, 64), 73: (128, 128, 64), 74: (128, 128, 64),
-    80: (128, 128, 64), 81: (128, 64, 64), 82: (128, 128, 64), 83: (128, 64, 64), 84: (128, 256, 64),
-    93: (128, 64, 64), 94: (128, 64, 64), 90: (128, 128, 64), 91: (128, 128, 64), 92: (128, 128, 64),
+    80: (128, 128, 64), 81: (128, 64, 64), 83: (128, 64, 64), 93: (128, 64, 64), 94: (128, 64, 64),      # conv_wreg.inl forms
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 72: (16, 16), 73: (8, 16), 74: (8, 16), 80: (8, 16), 81: (8, 16), 82: (8, 16), 83: (8, 16), 84: (8, 16), 93: (8, 16), 94: (8, 16), 90: (8, 16), 91: (8, 16), 92: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16)}
 
 
 def main():
