@@ -430,7 +430,7 @@ def main():
         layers.append(dict(rows=key[0], cin=key[1], cout=key[2], k=key[3], stride=key[4], groups=key[5],
                            launches_per_step=cnt // reps, us_per_launch=round(1e3 * ms / cnt, 1),
                            tflops=round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0))
-    roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16", achieved=round(achieved, 2), peak=peak,
+    roofline = dict(bound="mfma", kernel="w2c_conv_igemm_bf16 + w2c_conv3x3_wreg_bf16 (the conv family: every conv launch of the forward)", achieved=round(achieved, 2), peak=peak,
                     unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
                     launches_per_step=launches, kernel_ms_per_step=round(busy_ms, 4),
                     kernel_ms_sum_of_durations=round(conv_ms, 4), frac_by_sum_of_durations=round(achieved_sum / peak, 4),
@@ -439,7 +439,8 @@ def main():
                     time_note="launches of the value and the policy trunk overlap on two streams from layer2 on: kernel_ms_per_step "
                               "and frac use the UNION of the launch intervals (chip time spent in the family); the sum of the "
                               "per-launch durations counts shared wall time twice and is given beside it (the per-layer us_per_launch / tflops below "
-                              "are those shared-chip durations: a layer4 conv takes 38 us alone and 45 us beside the other trunk's)",
+                              "are those shared-chip durations: a layer4 conv takes 31 us alone and 39 us beside the other trunk's); peak is the guide's 2.5 PFLOP/s (2.4 GHz) -- "
+                              "back-to-back MFMAs on random bf16 operands deliver 1.86-1.94 PFLOP/s on this part (tools/ubench/mfma_rate.hip)",
                     algorithmic_gflop_per_step=round(conv_fl / 1e9, 2),
                     algorithmic_bytes_per_step=int(conv_bytes),
                     whole_forward_tflops=round(value * flop_per_img / 1e3, 2),

@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -2327,7 +2327,7 @@ int pick_variant(const ConvArgs& a, int groups) {
         // (its 7 us weight prologue is per launch); smaller problems stay on the ring kernel
         if (a.Cin == 64 && Cout == 64 && a.ygs == 64 && a.H % 4 == 0 && !a.y_f32 && !a.y8 && a.y && (long)a.M * (a.H / 4) * (a.W / 16) * groups >= 4096 &&
             (size_t)a.M * a.H * a.W * a.xcs * 2 < (1ull << 31) && (size_t)a.M * a.H * a.W * a.ycs * 2 < (1ull << 31))
-            return 50;
+            return w2c_option(W2C_OPT_REGW_FORM) == 2 ? 52 : 50;
         if (a.Cin == 64 && Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 38;
         if (a.Cin == 128 && Cout % 128 == 0 && tiles * (Cout / 128) >= 256) return 30;
         if (Cout % 64 == 0 && tiles * (Cout / 64) >= 64) return 36;

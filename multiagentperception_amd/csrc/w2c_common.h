@@ -91,6 +91,7 @@ enum W2COption {
     W2C_OPT_INWG_SPLITK,      // 1 (default) | 0: split-K convs with <= 12 splits as ONE launch (splits = waves, partials in LDS)
     W2C_OPT_WREG_MINCIN,      // 256 (default): 3x3 / s1 convs with Cin >= this go to the weights-to-registers kernel; 0 = never
     W2C_OPT_WREG_FORM,        // 0 (default): the library's per-layer choice | 80 / 81 / 83 / 93: that form wherever it fits
+    W2C_OPT_REGW_FORM,        // layer1 kernel: 1 = LDS-staged epilogue | 2 = register-direct epilogue (bit-identical)
     W2C_OPT_COUNT
 };
 int w2c_option(int id);
