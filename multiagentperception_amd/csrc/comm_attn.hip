@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const void* __restrict__ xv
 // reduction.  The one-wave-per-output form above serialises K/256 dependent iterations per row and
 // ran 76 us for M=20, K=4096, O=256 (r01_a profile); this form is bound by the 4 MB weight read.
 // MR = 20 rows per pass: cfg 2's 20 agent-images take ONE pass over the weight row (MR = 8 took three: 16.3 -> 14.7 us under graph replay, tools/bench_linear.py; the rest is the 20 wave reductions).
+// (amdgpu_waves_per_eu(2, 2): two K-slices of row loads in flight need ~110 VGPRs; two waves per SIMD is all this launch has anyway)
 template <int MR, bool XBF16>
-__global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restrict__ xv, int x_stride, int M, int K,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_widek_kernel(const void* __restrict__ xv, int x_stride, int M, int K,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            int O, int relu, float* __restrict__ y) {
     __shared__ float red[4][MR];
@@ -93,28 +94,48 @@ __global__ __launch_bounds__(256) void linear_widek_kernel(const void* __restric
         float acc[MR];
 #pragma unroll
         for (int r = 0; r < MR; ++r) acc[r] = 0.f;
-#pragma unroll 4
-        for (int k = tid * 4; k < K; k += 1024) {      // (unrolled: every load of up to 4 K-slices in flight -- the kernel is load latency)
-            const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wrow + k);
+        // All MR row loads of a K-slice (and of the next one) are issued before the first is used: written as a plain load-use loop the
+        // compiler sinks every load next to its FMAs and waits vmcnt(0) after each pair -- 40 dependent L2 round trips per workgroup.
+        auto slice = [&](int k, f32x4_t& wv, uint2 (&xb)[MR], f32x4_t (&xf)[MR]) {
+            wv = *reinterpret_cast<const f32x4_t*>(wrow + k);
 #pragma unroll
             for (int r = 0; r < MR; ++r) {
                 const int m = m0 + r < M ? m0 + r : M - 1;          // clamp: branch-free, duplicates discarded below
+                if (XBF16) xb[r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(xv) + (size_t)m * x_stride + k);
+                else xf[r] = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(xv) + (size_t)m * x_stride + k);
+            }
+        };
+        auto fma_slice = [&](const f32x4_t& wv, const uint2 (&xb)[MR], const f32x4_t (&xf)[MR]) {
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
                 float x0, x1, x2, x3;
                 if (XBF16) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(
-                        reinterpret_cast<const uint16_t*>(xv) + (size_t)m * x_stride + k);
-                    x0 = bf16_to_f32((uint16_t)(u.x & 0xFFFFu)); x1 = bf16_to_f32((uint16_t)(u.x >> 16));
-                    x2 = bf16_to_f32((uint16_t)(u.y & 0xFFFFu)); x3 = bf16_to_f32((uint16_t)(u.y >> 16));
+                    x0 = bf16_to_f32((uint16_t)(xb[r].x & 0xFFFFu)); x1 = bf16_to_f32((uint16_t)(xb[r].x >> 16));
+                    x2 = bf16_to_f32((uint16_t)(xb[r].y & 0xFFFFu)); x3 = bf16_to_f32((uint16_t)(xb[r].y >> 16));
                 } else {
-                    const f32x4_t u = *reinterpret_cast<const f32x4_t*>(
-                        reinterpret_cast<const float*>(xv) + (size_t)m * x_stride + k);
-                    x0 = u[0]; x1 = u[1]; x2 = u[2]; x3 = u[3];
+                    x0 = xf[r][0]; x1 = xf[r][1]; x2 = xf[r][2]; x3 = xf[r][3];
                 }
                 acc[r] = fmaf(x0, wv[0], acc[r]);
                 acc[r] = fmaf(x1, wv[1], acc[r]);
                 acc[r] = fmaf(x2, wv[2], acc[r]);
                 acc[r] = fmaf(x3, wv[3], acc[r]);
             }
+        };
+        f32x4_t wa, wb;
+        uint2 xba[MR], xbb[MR];
+        f32x4_t xfa[MR], xfb[MR];                          // (the unused operand type's arrays are dead code)
+        int k = tid * 4;
+        for (; k + 1024 < K; k += 2048) {                   // two K-slices per trip, both sets of loads in flight
+            slice(k, wa, xba, xfa);
+            slice(k + 1024, wb, xbb, xfb);
+            asm volatile("" ::: "memory");
+            fma_slice(wa, xba, xfa);
+            fma_slice(wb, xbb, xfb);
+        }
+        if (k < K) {
+            slice(k, wa, xba, xfa);
+            asm volatile("" ::: "memory");
+            fma_slice(wa, xba, xfa);
         }
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
