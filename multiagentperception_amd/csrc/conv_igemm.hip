@@ -2453,7 +2453,10 @@ extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int
     const int rc = fill_args(a, x, M, H, W, Cin, x_cstride, wfrag, Cout, 3, 1, groups, scale, shift, residual, relu, y, y_cstride, 0,
                              /*zero_page=*/x, y_group_stride);
     if (rc != W2C_OK) return rc;
-    if ((size_t)M * H * W * y_cstride * 2 >= (1ull << 31)) return W2C_E_ARG;      // 32-bit element offsets in the epilogue
+    // 32-bit element offsets in the epilogue: the whole output window (all groups' slabs) must lie within 2^31 elements of y
+    if ((size_t)M * H * W * y_cstride * 2 >= (1ull << 31) || y_group_stride < 0 ||
+        (unsigned long long)(groups - 1) * (unsigned long long)(y_group_stride ? y_group_stride : Cout) + (size_t)M * H * W * y_cstride >= (1ull << 31))
+        return W2C_E_ARG;
     if (form == 0) form = wreg_form(H, W, Cin, Cout);
     if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94) return W2C_E_ARG;
     w2c_clear_error();

@@ -86,10 +86,14 @@ class ConvPlan:
             self.wfrag = ops.pack_wfrag_device(self.w, self.cin)
 
     def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None, out=None, out_ch_off=0):
-        if (self.wfrag is not None and not out_f32 and out_groups is None
+        far = False                                  # group slabs further apart than the kernel's 32-bit output offsets reach
+        if out_groups is not None and len(out_groups) > 1:
+            span = out_groups[-1].data_ptr() - out_groups[0].data_ptr()
+            far = span < 0 or span // 2 + out_groups[0].numel() >= (1 << 31)
+        if (self.wfrag is not None and not out_f32 and not far
                 and ops.conv3x3_wreg_supported(x.shape[1], x.shape[2], self.cin, self.cout)):
             return ops.conv3x3_wreg(x, x_ch_off, self.cin, self.wfrag, self.cout, self.groups, self.scale, self.shift,
-                                    residual=residual, relu=self.relu, out=out, out_ch_off=out_ch_off)
+                                    residual=residual, relu=self.relu, out=out, out_ch_off=out_ch_off, out_groups=out_groups)
         # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
                               self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,

@@ -356,9 +356,29 @@ def conv3x3_wreg_supported(H, W, cin, cout):
 
 
 def conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, residual=None, relu=True, out=None, out_cstride=None,
-                 form=0, out_ch_off=0, _gstride=0):
+                 form=0, out_ch_off=0, _gstride=0, out_groups=None):
     """w2c_conv3x3_wreg_bf16: 3x3 / stride 1 / pad 1, bf16 NHWC in and out; `wfrag` from pack_wfrag_device.  Same tensor
-    conventions as conv_igemm (x_ch_off, out_ch_off, groups side by side unless _gstride)."""
+    conventions as conv_igemm (x_ch_off, out_ch_off, groups side by side unless _gstride; out_groups = one evenly spaced
+    tensor per group, e.g. the squeezer writing V into its slot of the all-gather buffer)."""
+    if out_groups is not None:
+        if out is not None or residual is not None or len(out_groups) != groups:
+            raise W2CError("conv3x3_wreg: out_groups excludes out/residual and needs one tensor per group")
+        g0 = out_groups[0]
+        _need_gpu(*out_groups)
+        gstride = 0
+        for i, t in enumerate(out_groups):
+            if t.shape != g0.shape or t.dtype != BF16 or g0.shape[3] < cout:
+                raise W2CError("conv3x3_wreg: out_groups tensors must share shape, be bf16 and have >= cout channels")
+            d = t.data_ptr() - g0.data_ptr()
+            if i == 1:
+                gstride = d // 2
+            if d != i * gstride * 2 or d % 16:
+                raise W2CError("conv3x3_wreg: out_groups tensors must be evenly spaced, 16-byte aligned")
+        if gstride == 0 and groups > 1:
+            raise W2CError("conv3x3_wreg: out_groups tensors alias")
+        conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, relu=relu, out=g0, out_cstride=g0.shape[3], form=form,
+                     _gstride=gstride if groups > 1 else 0)
+        return list(out_groups)
     dev = _need_gpu(x, wfrag, scale, shift, residual, out)
     M, H, W, xcs = x.shape
     if out_cstride is None:

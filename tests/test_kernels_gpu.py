@@ -1053,3 +1053,18 @@ def test_conv3x3_wreg_xcd_placement_leaves_results_bit_identical(lib_option):
         lib_option("W2C_XCD2D", mode)
         outs.append(ops.conv3x3_wreg(x_dev, 0, 512, wfrag, 512, 1, scale.to(_dev()), shift.to(_dev()), residual=res_dev, form=93).clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_conv3x3_wreg_out_groups_writes_each_group_into_its_own_tensor():
+    """the squeezer's agent-parallel form: one output tensor per group (slots of an all-gather buffer), evenly spaced"""
+    from multiagentperception_amd import ops
+    case = (0, 2, 16, 16, 256, 128, 2, False, True, 0, 0)
+    xs, ws, scale, shift, ress, x_dev, w_dev, res_dev = _wreg_setup(case, 99)
+    wfrag = ops.pack_wfrag_device(w_dev, 256)
+    sc, sh = scale.to(_dev()), shift.to(_dev())
+    side = ops.conv3x3_wreg(x_dev, 0, 256, wfrag, 128, 2, sc, sh)
+    buf = torch.full((2, 3, 2, 16, 16, 128), 5.0, dtype=BF16, device=_dev())      # [group][slot]: the groups' tensors are 3 slots apart
+    outs = ops.conv3x3_wreg(x_dev, 0, 256, wfrag, 128, 2, sc, sh, out_groups=[buf[0, 1], buf[1, 1]])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], side[..., :128]) and torch.equal(outs[1], side[..., 128:])
+    assert bool((buf[:, 0] == 5.0).all()) and bool((buf[:, 2] == 5.0).all())
