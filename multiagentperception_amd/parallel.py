@@ -131,6 +131,7 @@ class _ShardState:
         lo, hi = q_lo * B, (q_lo + n_loc) * B
         self.v_slot = self.v_all[lo:hi]
         self.k_slot = self.k_all[lo:hi]
+        self.pol_y = None               # policy conv5's output (segment A, static under graph replay): the heads' input
         self.graphs = {}
         self.out = {}
 
@@ -167,9 +168,9 @@ class AgentParallelForward:
     Returns (pred [n_loc*B, n_cls, H, W], prob [B, N, n_loc], action [B, n_loc], nnz [B])
     for the local query agents; N = global agent count.
 
-    Per step and rank ('softmax'): stem (eager: reads the caller's tensor) -> segment A: layer1..4 + both squeezers, the
-    value trunk's squeezer writing V straight into this rank's rows of the all-gather buffer -> async all-gather of V
-    (in place, RCCL) -> segment B: policy tail + heads, the projected keys written into this rank's rows of the key
+    Per step and rank ('softmax'): stem (eager: reads the caller's tensor) -> segment A: layer1..4 + both squeezers + policy
+    conv1..5 (on the policy chain's stream), the value trunk's squeezer writing V straight into this rank's rows of the
+    all-gather buffer -> async all-gather of V (in place, RCCL) -> segment B: the key / query heads, the projected keys written into this rank's rows of the key
     buffer (runs while V is on the wire) -> all-gather of K -> segment C: graph columns of the local queries, fusion,
     decoder convs -> upsample (eager: caller-owned output).  With model.use_hip_graph the three segments are replayed
     from captured HIP graphs (~45 launches -> 3); the collectives stay eager between them."""
@@ -215,7 +216,7 @@ class AgentParallelForward:
             if inference != "softmax":
                 return self._sparse(eng, st, inference, use_graph)
             v_work = _gather_inplace(st.v_all, self.rank, self.n_loc * B, self.group)
-            st.run("B", lambda: eng.policy_tail(st.pol, ch_off=0, outs=(st.k_slot, st.q_loc)), use_graph)   # under the V gather
+            st.run("B", lambda: self._segment_b(eng, st), use_graph)   # under the V gather
             k_work = _gather_inplace(st.k_all, self.rank, self.n_loc * B, self.group)
             exchange_wait(v_work)
             exchange_wait(k_work)
@@ -240,8 +241,23 @@ class AgentParallelForward:
                     dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
                 return amax
             eng.trunk.calibrate(st.s0, reduce_amax=_max_over_ranks)
-        st.run("A", lambda: tuple(eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol])), use_graph)
+        if eng.trunk.n8:
+            st.run("A", lambda: tuple(eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol])), use_graph)
+            st.pol_y = None
+        else:
+            # as in the one-GPU forward, policy conv1..5 ride the policy chain's stream beside the value chain (they were the whole of
+            # the sharded path's extra 0.09 ms per step when segment B ran them after the join); segment B keeps the heads
+            a = st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol],
+                                                          policy_next=(lambda pol: eng.policy_convs(pol, ch_off=0), lambda y: y))[1],),
+                       use_graph)
+            st.pol_y = a[0]
         return st
+
+    @staticmethod
+    def _segment_b(eng, st):
+        if st.pol_y is None:
+            return eng.policy_tail(st.pol, ch_off=0, outs=(st.k_slot, st.q_loc))
+        return eng.policy_heads(st.pol_y, outs=(st.k_slot, st.q_loc))
 
     def _sparse(self, eng, st, inference, use_graph=False):
         """'activated' / 'argmax_test' across ranks, handshake-ordered: tiny exchange of projected keys
@@ -249,7 +265,7 @@ class AgentParallelForward:
         xGMI.  self.last_exchange = (maps received, maps an all-gather would have received)."""
         from . import ops
         B, N = st.B, st.N
-        st.run("B", lambda: eng.policy_tail(st.pol, ch_off=0, outs=(st.k_slot, st.q_loc)), use_graph)
+        st.run("B", lambda: self._segment_b(eng, st), use_graph)
         k_work = _gather_inplace(st.k_all, self.rank, self.n_loc * B, self.group) if dist.is_initialized() else None
         q_all, q_work = (exchange_start(st.q_loc, self.group) if st.q_loc is not None else (None, None))
         exchange_wait(k_work)
