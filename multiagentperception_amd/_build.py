@@ -31,7 +31,13 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value"] + os.environ.get("W2C_EXTRA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+           "-Wno-unused-value",
+           # no SLP vectorisation => no packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel.  Found with several
+           # engines in flight (tools/inflight_lin.py): the LOW half of v_pk_fma_f32 results in the wide-K head kernel came out wrong
+           # (1e-3 .. 7e-2, a few elements, even rows = low halves only) whenever its waves shared a CU with another kernel's MFMA
+           # waves -- never alone, never with the scalar form.  The same IEEE results either way; packed f32 beside MFMAs is slower
+           # anyway (cdna_hip_programming.md, co-issue table).
+           "-fno-slp-vectorize"] + os.environ.get("W2C_EXTRA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -438,3 +438,34 @@ def test_first_forward_of_a_process_is_deterministic_under_the_concurrent_launch
                                  capture_output=True, text=True, timeout=600)
             assert out.returncode == 0, out.stderr[-2000:]
             assert ": 0 / 3 first forwards differ" in out.stdout, out.stdout[-2000:]
+
+
+def test_several_engines_in_flight_return_the_bits_of_one_forward_alone():
+    """Three models (same weights, own engines / buffers / graphs) launched round-robin on three streams: every output equals the
+    output of one forward alone.  Regression test for packed-f32 VALU beside another kernel's MFMA waves: built with SLP
+    vectorisation, fc.0's v_pk_fma_f32 returned wrong LOW halves (a few keys / queries off by 1e-3 .. 7e-2, hence every logit of
+    the forward) whenever its waves shared a CU with conv kernels -- i.e. only with several forwards in flight
+    (multiagentperception_amd/_build.py: -fno-slp-vectorize; tools/inflight_check.py is this loop stand-alone)."""
+    from ptsemseg.models import get_model
+    F, n, b, size = 3, 5, 4, 512
+    cfg, _ = _cfg(dict(arch="MIMOcom", agent_num=n, size=size, model_over={}))
+    models = []
+    for _ in range(F):
+        m = get_model(cfg, 11)
+        filler.apply_to_module(m)
+        m = m.to("cuda:0").eval()
+        m.use_hip_graph = True
+        models.append(m)
+    x = torch.from_numpy(filler.synthetic_frames(b, n, size, size, 4242)).cuda()
+    ref = [t.clone() for t in models[0](x, training=False, MO_flag=True, inference="softmax") if torch.is_tensor(t)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(F)]
+    for rnd in range(10):
+        outs = []
+        for i in range(2 * F):
+            with torch.cuda.stream(streams[i % F]):
+                outs.append(models[i % F](x, training=False, MO_flag=True, inference="softmax"))
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            for j, (got, want) in enumerate(zip([t for t in o if torch.is_tensor(t)], ref)):
+                assert torch.equal(got, want), "round %d, forward %d (engine %d), output %d differs from the forward alone" % (rnd, i, i % F, j)
