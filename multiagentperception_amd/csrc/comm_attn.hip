@@ -137,10 +137,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("" ::: "memory");
             fma_slice(wa, xba, xfa);
         }
+        // the MR butterflies level by level (MR independent ds_bpermute per level in flight; row by row, with lane 0's store in
+        // between, the compiler waits lgkmcnt(0) after each of the 6 MR shuffles), then lane 0 stores all.  Same order of additions.
 #pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            const float sres = wave_sum(acc[r]);
-            if (lane == 0) red[wave][r] = sres;
+        for (int o = 32; o > 0; o >>= 1) {
+            float t[MR];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) t[r] = __shfl_xor(acc[r], o, 64);
+#pragma unroll
+            for (int r = 0; r < MR; ++r) acc[r] += t[r];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < MR; ++r) red[wave][r] = acc[r];
         }
         __syncthreads();
         if (tid < MR && m0 + tid < M) {
