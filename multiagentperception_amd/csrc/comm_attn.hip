@@ -321,7 +321,17 @@ __device__ __forceinline__ bool graph_column(const float* __restrict__ query, co
         float d = trow[Dq];
         if (query) {
             const float* qrow = query + (size_t)(ql * B + b) * Dq;   // rows of the produced query agents only
-            for (int j = 0; j < Dq; ++j) d = fmaf(trow[j], qrow[j], d);
+            // 16 key / 16 query values in flight per step (a plain j loop issues one dependent pair of loads at a time: 32 L2 round
+            // trips per column); the FMAs stay in j order
+            int j = 0;
+            for (; j + 16 <= Dq; j += 16) {
+                float tv[16], qv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { tv[u] = trow[j + u]; qv[u] = qrow[j + u]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) d = fmaf(tv[u], qv[u], d);
+            }
+            for (; j < Dq; ++j) d = fmaf(trow[j], qrow[j], d);
         } else {
             for (int j = 0; j < Dq; ++j) d += trow[j];                 // all-ones query (agent.py:1143,1370)
         }
