@@ -36,6 +36,7 @@ def _fold_bn(bn, conv_bias=None):
 
 
 _USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
+_HEADS_AFTER_JOIN = bool(os.environ.get('W2C_HEADS_AFTER_JOIN'))
 
 
 def _pack_w(conv_weight):
@@ -568,10 +569,14 @@ class CommEngine:
             sq = self.trunk.after_stem(s0)
             keys, querys = self.policy_tail(sq)
             return sq, keys, querys
-        # The policy chain's side stream carries on with policy conv1..5 beside the value chain; the HEADS run after the join, on
-        # the forward's own stream.  (With the heads on the side stream too, the first forward of a process delivered a few stale
-        # rows of fc.0's input to w2c_linear_f32 in 5 of 8 processes -- tools/stress_first_forward.py, profiles/r03_concurrency.txt --
-        # although every producer was on the same stream; conv -> conv hand-offs on the side stream never showed it.)
+        # The policy chain's side stream carries on with policy conv1..5 AND the key / query heads beside the value chain (1.1465-1.150 ->
+        # 1.1426-1.1457 ms, tools/ab_heads.sh).  Round 3 first kept the heads behind the join: on the side stream the first forward of
+        # a process delivered a few wrong fc.0 outputs in 5 of 8 processes.  The cause was found later -- packed-f32 FMAs of the head
+        # kernel beside the value chain's MFMA waves; the library is built without them now, and
+        # tools/stress_first_forward.py reports 0 of 29 first forwards differing in this form.  W2C_HEADS_AFTER_JOIN=1 restores the old one.
+        if not _HEADS_AFTER_JOIN:
+            sq, (keys, querys) = self.trunk.after_stem(s0, policy_next=(lambda s: self.policy_heads(self.policy_convs(s)), lambda r: r))
+            return sq, keys, querys
         sq, (keys, querys) = self.trunk.after_stem(s0, policy_next=(self.policy_convs, self.policy_heads))
         return sq, keys, querys
 
