@@ -443,8 +443,8 @@ extern "C" int w2c_conv_block_c64(const uint16_t* x, int M, int H, int W, int x_
     const int ring_bytes = (a.NX + a.NT) * 128 + 4 * 32 * 128 + 1024;
     const int lds = ring_bytes > WBYTES ? ring_bytes : WBYTES;
     if (lds > 160 * 1024) return W2C_E_ARG;
-    static unsigned long long attr_mask = 0;
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_c64_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef W2C_BLOCK_ABLATIONS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_c64_fused_kernel<11>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -454,7 +454,7 @@ extern "C" int w2c_conv_block_c64(const uint16_t* x, int M, int H, int W, int x_
         hipDeviceProp_t prop;
         n_cu[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                              ? prop.multiProcessorCount : 256;
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     int cus = n_cu[dev & 63];
     if (max_workgroups > 0 && max_workgroups < cus) cus = max_workgroups;

@@ -1238,13 +1238,13 @@ int launch_s2patch(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int epi = 128 * (BN + 4) * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_patch_kernel<BN, RS, F8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL((conv3x3s2_patch_kernel<BN, RS, F8>), dim3(a.ntm * a.ntn, groups), dim3(512), lds, s, a);
     return w2c_launch_status();
@@ -1858,18 +1858,18 @@ __global__ __launch_bounds__(256) void conv3x3_c64_regw2_kernel(ConvArgs p) {
 template <bool HAS_RES, int VER = 1>
 int launch_regw(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int lds = 4 * (2 * 14 * 1024 + 8 * 1024) + 512;    // 4 waves' patch/residual buffers + scale/shift
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     static int n_cu[64] = {0};
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(VER == 2 ? reinterpret_cast<const void*>(&conv3x3_c64_regw2_kernel<HAS_RES>)
                                            : reinterpret_cast<const void*>(&conv3x3_c64_regw_kernel<HAS_RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipDeviceProp_t prop;
         n_cu[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                              ? prop.multiProcessorCount : 256;
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const long tiles = (long)a.M * (a.H / 4) * (a.W / 16);
     int wgs = (n_cu[dev & 63] + groups - 1) / groups;            // one 4-wave workgroup per CU, split over the groups
@@ -1905,13 +1905,13 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int epi = TH * TW * (BN + 4) * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS");
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     dim3 grid(a.ntm * a.ntn, groups);
     const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);            // (tests and tools/ab_xcd2d.sh switch it through w2c_set_option)
@@ -2138,11 +2138,13 @@ int launch_conv_inwg_splitk(ConvArgs& a, int groups, int ksplit, hipStream_t s) 
     a.ntn = a.Cout / 32;
     a.n_split = ksplit;
     const int lds = ksplit * BM_ * 36 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_inwg_splitk_kernel<BM_, UF, MAXT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL((conv_inwg_splitk_kernel<BM_, UF, MAXT>), dim3(a.ntm * a.ntn, groups), dim3(64 * ksplit), lds, s, a);
     return w2c_launch_status();
@@ -2211,13 +2213,13 @@ int launch_conv(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int lds = ring > conv_lds_bytes<BM, BN, BK, STAGES>() ? ring : conv_lds_bytes<BM, BN, BK, STAGES>();
     static_assert(lds <= 160 * 1024, "LDS");
     // dynamic LDS above 64 KiB needs the attribute once per device; keep a per-device bit.
-    static unsigned long long attr_mask = 0;   // benign race: every thread writes the same attribute
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8, DUAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     dim3 grid(a.ntm * a.ntn, groups);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, STAGES, false, F8, DUAL>), grid, dim3(64 * WM * WN), lds, s, a);

@@ -413,12 +413,12 @@ static int wgrad_impl(const uint16_t* x, int M, int H, int W, int Cin, int x_cst
     dim3 grid(a.nct_o * a.nct_i, a.nseg, groups);
     if (ksize == 3 && stride == 1 && a.Ho % 8 == 0 && a.Wo % 16 == 0 && w2c_option(W2C_OPT_WGRAD_PATCH) != 0) {
         constexpr int lds = 2 * (23 * 1024 + 128 * 128);
-        static unsigned long long attr_mask = 0;
+        static std::atomic<unsigned long long> attr_mask{0};
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!((attr_mask >> (dev & 63)) & 1ull)) {
+        if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_mask |= 1ull << (dev & 63);
+            attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
         hipLaunchKernelGGL(conv_wgrad_patch_kernel, grid, dim3(256), lds, s, a);
     } else if (ksize == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), 0, s, a);

@@ -369,12 +369,12 @@ int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
     constexpr int xchg = KS > 1 ? NN * KS * 16384 : 0;
     constexpr int lds = (patch > xchg ? patch : xchg) + NN * KS * 512;
     static_assert(lds <= 160 * 1024, "LDS");
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);
     const long wbytes = (long)a.Cout * 9 * a.Cin * 2;

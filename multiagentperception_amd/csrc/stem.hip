@@ -1115,13 +1115,13 @@ template <int COUT, bool TRAIN = false>
 int launch_stem(const float* x, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                 const float* shift, uint16_t* y, hipStream_t s) {
     constexpr int lds = PATCH_BYTES + 256 * COUT * 2;
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<COUT, TRAIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     dim3 grid((H / 2) / 8, N * B);
     hipLaunchKernelGGL((stem_kernel<COUT, TRAIN>), grid, dim3(256), lds, s, x, B, N, H, W, w, scale, shift, y);
@@ -1163,13 +1163,13 @@ template <int COUT, bool U8, int BAND, int NW>
 static int launch_stem_pool_band(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                                  const float* shift, uint16_t* y, hipStream_t s) {
     constexpr int lds = fp_bytes<BAND>() + (BAND + 1) * 33 * COUT * 2;
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<COUT, U8, BAND, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     dim3 grid((H / 2) / BAND, N * B);
     hipLaunchKernelGGL((stem_pool_kernel<COUT, U8, BAND, NW>), grid, dim3(64 * NW), lds, s, x, mean, B, N, H, W, w, scale, shift, y);
@@ -1189,16 +1189,16 @@ template <bool U8>
 static int launch_stem_pool3(const void* x, FrameMean mean, int B, int N, int H, int W, const uint16_t* w, const float* scale,
                              const float* shift, uint16_t* y, hipStream_t s) {
     constexpr int lds = 3 * fp_bytes<8>() + 4 * 512 + (U8 ? 1536 : 0);
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     static int n_cu[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool3_kernel<U8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int cu = 0;
         if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
         n_cu[dev & 63] = cu;
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int total = N * B * ((H / 2) / 8) * ((W / 2) / 32);
     int wgs = n_cu[dev & 63];

@@ -187,12 +187,12 @@ extern "C" int w2c_stem_wgrad_bf16(const uint16_t* x_nhwc3, int M, int H, int W,
     const int nblocks = M * (a.Ho / SW_TH) * (a.Wo / SW_TW);
     a.blocks_per_seg = (nblocks + a.nseg - 1) / a.nseg;
     constexpr int lds = 65536 + 3 * SW_PR * SW_PC * 2 + 80;
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_mask >> (dev & 63)) & 1ull)) {
+    if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_mask |= 1ull << (dev & 63);
+        attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(a.nseg), dim3(256), lds, s, a);

@@ -37,6 +37,12 @@ def _fold_bn(bn, conv_bias=None):
 
 _USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
 _HEADS_AFTER_JOIN = bool(os.environ.get('W2C_HEADS_AFTER_JOIN'))
+# the remaining A/B switches, read once at import (never on the launch path)
+_NO_SPLITK = bool(os.environ.get('W2C_NO_SPLITK'))
+_NO_DUAL = bool(os.environ.get('W2C_NO_DUAL'))
+_FP8_SERIAL = bool(os.environ.get('W2C_FP8_SERIAL'))
+_NO_TAIL_OVERLAP = bool(os.environ.get('W2C_NO_TAIL_OVERLAP'))
+_NO_GRAPH_FUSE = bool(os.environ.get('W2C_NO_GRAPH_FUSE'))
 
 
 def _pack_w(conv_weight):
@@ -98,7 +104,7 @@ class ConvPlan:
         # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
                               self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,
-                              ksplit=None if os.environ.get('W2C_NO_SPLITK') else 0, out_groups=out_groups, out=out,
+                              ksplit=None if _NO_SPLITK else 0, out_groups=out_groups, out=out,
                               out_ch_off=out_ch_off)
 
 
@@ -152,7 +158,7 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
     # kernel when the map is large enough to pay for its second accumulator set (>= 16 k output pixels).  Same bits either way.
     Ho, Wo = (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2
     patch_ok = Ho % 8 == 0 and Wo % 16 == 0 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
-    if os.environ.get("W2C_NO_DUAL") or not (patch_ok or x.shape[0] * Ho * Wo >= 16384):
+    if _NO_DUAL or not (patch_ok or x.shape[0] * Ho * Wo >= 16384):
         if f8:
             return (c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1],
                     ds.run(x, x_ch_off=x_ch_off)[0])
@@ -374,7 +380,7 @@ class TrunkPlan:
         # branch when the forward is captured into a HIP graph), so its half-size launches fill the CUs the fp8 half
         # leaves idle (320-640 workgroups per launch on 512 slots).
         main = torch.cuda.current_stream(p.device)
-        side = self._side_stream(p.device) if (self.fp8["rest"] and not os.environ.get("W2C_FP8_SERIAL")) else None
+        side = self._side_stream(p.device) if (self.fp8["rest"] and not _FP8_SERIAL) else None
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -565,7 +571,7 @@ class CommEngine:
         (Measured and rejected, profiles/r02_concurrency_experiments.txt: running the policy encoder's layer4 alone first so
         that the policy tail overlaps the value encoder's layer4 on a second stream -- 1.2988 vs 1.3024 ms, no gain: the
         tail's launches are inefficient, not idle, and a concurrent kernel only shares their CUs.)"""
-        if self.trunk.n8 or os.environ.get("W2C_NO_TAIL_OVERLAP"):
+        if self.trunk.n8 or _NO_TAIL_OVERLAP:
             sq = self.trunk.after_stem(s0)
             keys, querys = self.policy_tail(sq)
             return sq, keys, querys
@@ -583,7 +589,7 @@ class CommEngine:
     def graph_and_low(self, sq_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
         """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion, decoder convs
         (everything up to the low-resolution logits)."""
-        if os.environ.get("W2C_NO_GRAPH_FUSE"):            # A/B: the two launches this replaces (same bits)
+        if _NO_GRAPH_FUSE:            # A/B: the two launches this replaces (same bits)
             pack, prob, action, nnz = ops.graph_outputs(sq_all.device, B, N, q_n)
             p2, coef, a2, n2 = ops.comm_graph_projected(querys_local, keys_all, B, N, self.who, mode, q_lo=q_lo, q_n=q_n)
             prob.copy_(p2); action.copy_(a2); nnz.copy_(n2)

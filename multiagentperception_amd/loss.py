@@ -28,22 +28,36 @@ _LABEL_CHECK_EVERY = 256
 _bad_labels = {}            # device -> [accumulated count tensor, calls since the last read, calls]
 
 
+_CHECK_LABELS_EVERY_CALL = __import__("os").environ.get("W2C_CHECK_LABELS") == "1"      # read once; tests flip the module attribute
+
+
 def _note_bad_labels(out3):
-    import os
+    """Off the hot path: the count is added on the device (no sync), and read back on the first call, then every
+    _LABEL_CHECK_EVERY calls.  The error names the range of calls it covers; in a distributed run the flag is all-reduced (MAX)
+    first, so every rank raises together instead of one rank leaving the others in the next collective.  Skipped while a HIP graph
+    is being captured (a captured training step checks labels through W2C_CHECK_LABELS runs outside capture)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
     dev = out3.device
     st = _bad_labels.get(dev)
     if st is None:
-        st = _bad_labels[dev] = [torch.zeros((), dtype=torch.float64, device=dev), 0, 0]
+        st = _bad_labels[dev] = [torch.zeros((), dtype=torch.float64, device=dev), 0, 0, 1]
     st[0] += out3[2].double()
     st[1] += 1
     st[2] += 1
-    if st[2] == 1 or st[1] >= _LABEL_CHECK_EVERY or os.environ.get("W2C_CHECK_LABELS") == "1":
-        st[1] = 0
-        bad = int(st[0].item())
-        if bad:
-            st[0].zero_()
-            raise ValueError("cross_entropy2d: %d target values are outside [0, n_classes) and are not the ignore index %d "
-                             "(torch's cross_entropy asserts on these; this kernel drops them): check the label map" % (bad, IGNORE_INDEX))
+    if st[2] == 1 or st[1] >= _LABEL_CHECK_EVERY or _CHECK_LABELS_EVERY_CALL:
+        first, last = st[3], st[2]
+        st[1], st[3] = 0, st[2] + 1
+        flag = st[0].clone()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad_any, bad = int(flag.item()), int(st[0].item())
+        st[0].zero_()
+        if bad_any:
+            raise ValueError("cross_entropy2d: %d target values (this rank; loss calls %d..%d) are outside [0, n_classes) and are "
+                             "not the ignore index %d (torch's cross_entropy asserts on these; this kernel drops them): check "
+                             "the label map" % (bad, first, last, IGNORE_INDEX))
 
 
 class _CrossEntropy2dFn(torch.autograd.Function):

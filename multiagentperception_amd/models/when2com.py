@@ -50,8 +50,15 @@ class _EngineCacheMixin:
         if ts is None:
             ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
         v = len(ts)
-        for t in ts:
-            v += t._version
+        try:
+            for t in ts:
+                v += t._version
+        except RuntimeError:
+            # inference tensors (a model built or loaded under torch.inference_mode()) track no version counter: such weights
+            # cannot be modified in place either, so the always-cached behaviour is correct for them.  (DataParallel replicas see
+            # broadcast COPIES with a constant version: stale-weight detection does nothing there -- replicas are rebuilt by
+            # every forward anyway, nn.DataParallel.replicate.)
+            return -1
         return v
 
     def train(self, mode=True):

@@ -61,7 +61,7 @@ def test_out_of_range_labels_raise_through_the_loss_function(monkeypatch):
     """F.cross_entropy device-asserts on a label outside [0, C) that is not 250 (the reference); the kernel drops and counts them and
     the loss function surfaces the count: on the first call of a process, periodically after that, every call with W2C_CHECK_LABELS=1."""
     from multiagentperception_amd import loss as L
-    monkeypatch.setenv("W2C_CHECK_LABELS", "1")
+    monkeypatch.setattr(L, "_CHECK_LABELS_EVERY_CALL", True)
     logits, target = _case(2, 11, 32, 32, seed=3)
     L.cross_entropy2d(logits, target)                      # clean labels: fine
     target[1, 4, 4] = 255

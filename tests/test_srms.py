@@ -11,7 +11,6 @@ import pytest
 import torch
 
 from oracle import filler
-from oracle import diag_forward as diag
 from oracle import when2com_oracle as orc
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -114,10 +113,10 @@ def test_hip_forward_matches_reference_vectors_and_oracle(case):
         pred, prob, action = res[0].cpu(), res[1].cpu(), res[2].cpu()
         pre = mode + "_"
         assert prob.shape == (b, 1, nk) and pred.shape == (b, 11, s, s) and pred.dtype == torch.float32
-        # P within 2e-2, or 2.5x what bf16 storage alone loses on this input (CPU emulation) where that is larger
-        with diag.bf16_storage():
-            eref = fwd(sd, x, training=False, inference=mode, **kw)
-        p_tol = max(2e-2, 2.5 * float((eref[1] - ref[1]).abs().max()))
+        # P: the FIXED family numbers of DESIGN.md section 4 (tests/test_forward_gpu.py TOL) -- 2.5e-2 with a query net,
+        # 6.5e-2 for `query: False` (all-ones query, scores ~30); no emulation of the product scales them
+        p_tol = 2.5e-2 if case["has_query"] else 6.5e-2
+        print("%s %s: max|dP| vs reference vector %.3e (tol %.1e)" % (case["name"], mode, float(np.abs(prob.numpy() - g[pre + "prob"]).max()), p_tol))
         np.testing.assert_allclose(prob.numpy(), g[pre + "prob"], atol=p_tol)
         if mode == "activated":                                     # returns W * (W > 0.2); fixtures keep 0.04 from the threshold
             np.testing.assert_allclose(action.numpy(), g[pre + "action"], atol=p_tol)
