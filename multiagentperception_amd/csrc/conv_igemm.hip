@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -1925,6 +1925,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
 }
 
 #include "conv_wreg.inl"
+#include "conv_regh.inl"
 
 template <int BM, int BN, int BK, int STAGES>
 constexpr int conv_lds_bytes() {
@@ -2269,6 +2270,8 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
         case 52: return launch_regw2_any(a, groups, s);
+        // layer1, two waves per SIMD (conv_regh.inl; `w` in w2c_pack_wfrag_bf16 order)
+        case 54: return launch_regh_any(a, groups, s);
         // stride-2 3x3 on polyphase halo patches (here without the fused downsample)
         case 60: return launch_s2patch<64, 3, false>(a, groups, s);
         case 61: return launch_s2patch<128, 2, false>(a, groups, s);
@@ -2437,6 +2440,8 @@ extern "C" int w2c_pack_wfrag_bf16(const uint16_t* w, uint16_t* wfrag, int group
 // A function of the layer geometry only.
 static int wreg_form(int H, int W, int Cin, int Cout) {
     if (H <= 0 || W <= 0 || (H % 8) != 0 || (W % 16) != 0 || (Cin % 64) != 0 || (Cout % 64) != 0) return 0;
+    // layer1 (Cin = Cout = 64): the two-waves-per-SIMD register-resident kernel (conv_regh.inl), bit-identical to the ring kernels
+    if (Cin == 64 && Cout == 64) return w2c_option(W2C_OPT_L1_FORM) == 54 ? 54 : 0;
     const int mincin = w2c_option(W2C_OPT_WREG_MINCIN);
     if (mincin <= 0 || Cin < mincin) return 0;
     const int forced = w2c_option(W2C_OPT_WREG_FORM);
@@ -2460,7 +2465,7 @@ extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int
         (unsigned long long)(groups - 1) * (unsigned long long)(y_group_stride ? y_group_stride : Cout) + (size_t)M * H * W * y_cstride >= (1ull << 31))
         return W2C_E_ARG;
     if (form == 0) form = wreg_form(H, W, Cin, Cout);
-    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94) return W2C_E_ARG;
+    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94 && form != 54) return W2C_E_ARG;
     w2c_clear_error();
     return launch_variant(form, a, groups, reinterpret_cast<hipStream_t>(stream));
 }

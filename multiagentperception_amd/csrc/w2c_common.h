@@ -93,6 +93,9 @@ enum W2COption {
     W2C_OPT_WREG_MINCIN,      // 256 (default): 3x3 / s1 convs with Cin >= this go to the weights-to-registers kernel; 0 = never
     W2C_OPT_WREG_FORM,        // 0 (default): the library's per-layer choice | 80 / 81 / 83 / 93: that form wherever it fits
     W2C_OPT_REGW_FORM,        // layer1 kernel: 1 = LDS-staged epilogue | 2 = register-direct epilogue (bit-identical)
+    W2C_OPT_REGH_WGS,         // > 0: workgroups per group of the two-waves-per-SIMD layer1 kernel (tests: odd run lengths)
+    W2C_OPT_REGH_FORM,        // 0 (default) | 1 | 2 | 3: A/B forms of the two-waves-per-SIMD layer1 kernel (conv_regh.inl)
+    W2C_OPT_L1_FORM,          // layer1 (Cin = Cout = 64) through w2c_conv3x3_wreg_bf16: 54 (default) = conv3x3_c64_regh_kernel | 0 = not offered
     W2C_OPT_COUNT
 };
 int w2c_option(int id);

@@ -280,6 +280,49 @@ def test_layer1_kernel_forms_are_bit_identical_with_residual_and_relu():
             assert torch.equal(a, c) and torch.equal(b, a), (res is not None, relu)
 
 
+@pytest.mark.parametrize("M,G,H,W,wgs,form", [(6, 2, 64, 64, 0, 0), (3, 1, 32, 48, 0, 0), (5, 2, 40, 32, 7, 0), (2, 2, 128, 128, 0, 0),
+                                              (1, 1, 8, 16, 0, 0), (20, 2, 32, 32, 37, 0), (5, 2, 40, 32, 7, 7), (6, 2, 64, 64, 0, 1),
+                                              (20, 2, 32, 32, 37, 5)])
+def test_layer1_two_waves_per_simd_kernel_is_bit_identical(M, G, H, W, wgs, form, lib_option):
+    """conv3x3_c64_regh_kernel (round 4: half the output channels per wave, two waves per SIMD, one shared halo patch per 8 x 16 tile,
+    fragment-packed weights, form 54 of w2c_conv3x3_wreg_bf16) against the one-wave-per-SIMD form (variant 50, where it accepts the
+    shape) and the ring kernel (variant 38): same MFMA sequence, same epilogue arithmetic -> torch.equal; with and without residual /
+    ReLU; even and odd workgroup counts (uneven tile runs, image boundaries inside a run); repeated (race check)."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(54 + M + H)
+    x = torch.randn(M, H, W, G * 64, generator=gen).to(BF16).to(_dev())
+    r = torch.randn(M, H, W, G * 64, generator=gen).to(BF16).to(_dev())
+    w = (torch.randn(G, 64, 9 * 64, generator=gen) * 0.06).to(BF16).to(_dev())
+    sc = (torch.rand(G * 64, generator=gen) + 0.5).to(_dev())
+    sc[3] = -sc[3]
+    sh = (torch.randn(G * 64, generator=gen) * 0.3).to(_dev())
+    wf = ops.pack_wfrag_device(w, 64)
+    assert ops.conv3x3_wreg_supported(H, W, 64, 64)
+    if wgs:
+        lib_option("W2C_REGH_WGS", wgs)
+    if form:
+        lib_option("W2C_REGH_FORM", form)          # the kernel's A/B forms: 3-deep patch ring, deeper fragment prefetch, early residual
+    for res in (r, None):
+        for relu in (True, False):
+            ref = ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=res, relu=relu, variant=38)
+            got = ops.conv3x3_wreg(x, 0, 64, wf, 64, G, sc, sh, residual=res, relu=relu, form=54)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (res is not None, relu)
+            for _ in range(5):
+                again = ops.conv3x3_wreg(x, 0, 64, wf, 64, G, sc, sh, residual=res, relu=relu)      # form 0: the library's choice = 54
+                torch.cuda.synchronize()
+                assert torch.equal(again, ref)
+    if H % 4 == 0 and W % 16 == 0:
+        a = ops.conv_igemm(x, 0, 64, w, 64, 3, 1, G, sc, sh, residual=r, relu=True, variant=50)
+        assert torch.equal(a, ops.conv3x3_wreg(x, 0, 64, wf, 64, G, sc, sh, residual=r, relu=True, form=54))
+    # a window of a wider tensor: input channels [64, 64 + 64 G) of 64 (G + 2), output into channels [64, ...) of a wider buffer
+    xw = torch.randn(M, H, W, 64 * (G + 2), generator=gen).to(BF16).to(_dev())
+    out = torch.zeros(M, H, W, 64 * (G + 1), dtype=BF16, device=_dev())
+    ops.conv3x3_wreg(xw, 64, 64, wf, 64, G, sc, sh, relu=True, out=out, out_ch_off=64)
+    ref = ops.conv_igemm(xw, 64, 64, w, 64, 3, 1, G, sc, sh, relu=True, variant=38)
+    assert torch.equal(out[..., 64:], ref) and float(out[..., :64].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,hw,stride,ks", [(64, 64, 32, 1, 3), (128, 128, 32, 1, 3), (256, 128, 16, 1, 3), (512, 512, 16, 1, 3),
                                                    (128, 256, 32, 2, 3), (256, 512, 16, 2, 1), (64, 128, 64, 2, 3)])
 def test_conv_result_is_independent_of_tile_variant_and_image_count(cin, cout, hw, stride, ks):

@@ -13,6 +13,7 @@ BF16 = torch.bfloat16
 # name, M, H, W, Cin, Cout, ks, stride, groups, residual
 LAYERS = [
     ("l1 64->64 @128 g2 res", 20, 128, 128, 64, 64, 3, 1, 2, True),
+    ("l1 64->64 @128 g2", 20, 128, 128, 64, 64, 3, 1, 2, False),
     ("l2.0 64->128 s2 g2", 20, 128, 128, 64, 128, 3, 2, 2, False),
     ("l2 ds 1x1 s2 g2", 20, 128, 128, 64, 128, 1, 2, 2, False),
     ("l2 128->128 @64 g2 res", 20, 64, 64, 128, 128, 3, 1, 2, True),
@@ -37,10 +38,10 @@ LAYERS = [
 ]
 VALID = {  # variant -> (BM, BN, BK)
     0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
-    30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64),
+    30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64), 52: (64, 64, 64), 54: (128, 64, 64),
     80: (128, 128, 64), 81: (128, 64, 64), 83: (128, 64, 64), 93: (128, 64, 64), 94: (128, 64, 64),      # conv_wreg.inl forms
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 52: (4, 16), 54: (8, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16)}
 
 
 def main():
@@ -65,11 +66,11 @@ def main():
         cells = []
         for v in variants:
             bm, bn, bk = VALID[v]
-            if (v in (38, 39, 50) and cin != 64) or (v == 50 and cout != 64) or (v == 51 and (cin != 128 or cout != 128)) or cout % bn or cin % bk or (v in PATCH_GEOM and (ks != 3 or st != 1 or H % PATCH_GEOM[v][0] or W % PATCH_GEOM[v][1])):
+            if (v in (38, 39, 50, 52, 54) and cin != 64) or (v in (50, 52, 54) and cout != 64) or (v == 51 and (cin != 128 or cout != 128)) or cout % bn or cin % bk or (v in PATCH_GEOM and (ks != 3 or st != 1 or H % PATCH_GEOM[v][0] or W % PATCH_GEOM[v][1])):
                 cells.append("%16s" % "-")
                 continue
             wv = w
-            if v >= 80:
+            if v >= 80 or v == 54:
                 if f32:
                     cells.append("%16s" % "-")
                     continue
