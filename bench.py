@@ -509,7 +509,7 @@ def main():
         comm_us = 1e6 * (time.perf_counter() - t0) / n_it
         result["comm"] = dict(backend=("rccl" if args.backend == "nccl" else "gloo"), ranks=world,
                               us_per_step_unoverlapped=round(comm_us, 1),
-                              v_shard_bytes=int(st.v_slot.numel() * 2), k_shard_bytes=int(st.k_slot.numel() * 4),
+                              v_shard_bytes=int(st.v_slot.numel() * st.v_slot.element_size()), k_shard_bytes=int(st.k_slot.numel() * 4),
                               note="all-gather of V (bf16, written in place by the squeezer) + projected keys; in the timed "
                                    "step the V gather runs under the policy tail")
 

@@ -341,6 +341,46 @@ int w2c_comm_graph_fuse(const float* query, const float* tproj, int B, int N, in
                         uint16_t* out, int out_cstride, w2c_stream_t stream);
 
 
+/* ---- K5, round 4: fc.0 of the key / query heads (agent.py:150-151) on the f32 matrix pipe (v_mfma_f32_32x32x2_f32: exact f32).
+ * x     : bf16 [M <= 64][x_stride] policy map rows (K = 4096 features each)
+ * wfrag : f32 fc.0 weights of all heads stacked along O ([O][K]), FRAGMENT-PACKED:
+ *         wfrag[((o / 32) * (K / 8) + q) * 256 + (half * 32 + o % 32) * 4 + e] = W[o][8 q + 4 half + e]
+ * part  : f32 [ksplit][M][O] split-K partial sums (no bias, no ReLU); K % (128 ksplit) == 0, O % 32 == 0
+ * w2c_head_tail2p_f32 = w2c_head_tail2_f32 reading its fc.0 output as h0 = relu(sum_p part[p] + b0) (added in p order). */
+int w2c_head_fc0_mfma_f32(const uint16_t* x, int x_stride, int M, int K, const float* wfrag, int O, int ksplit,
+                          float* part, w2c_stream_t stream);
+int w2c_head_tail2p_f32(const float* part, int n_part, long long part_stride, const float* b0, int h0_stride, int M, int K1, int H1,
+                        int col_off_a, const float* w1t_a, const float* b1_a, const float* w2t_a, const float* b2_a, int O_a,
+                        float* out_a,
+                        int col_off_b, const float* w1t_b, const float* b1_b, const float* w2t_b, const float* b2_b, int O_b,
+                        float* out_b, w2c_stream_t stream);
+
+/* K6 + K7 with the decoder's first conv taken through the fusion by LINEARITY (round 4; agent.py:276-284, backbone.py:150-152):
+ *   u    : f32 NHWC rows [N*B][hw][u_cstride], agent-major: U[k] = conv0 WITHOUT bias of agent k's value map, channels [0, C);
+ *          MIMOcomWho (decoder input cat(fused, V[q]), agent.py:1382): channels [own_off, own_off + C) = the conv of V with the
+ *          second half of conv0's filters; own_off < 0: none
+ *   out  : bf16 NHWC rows [q_n*B][hw][out_cstride]: row (q*B+b) = relu(sum_k coef[b,k,q] * u[k*B+b] (+ u_own[(q_lo+q)*B+b]) + bias)
+ *          = relu(conv0(fused map)), summed in f32 and rounded once; graph outputs as in w2c_comm_graph_fuse. */
+int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
+                          float thres, float tie_bias, int q_lo, int q_n,
+                          float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                          const float* u, int u_cstride, int hw, int C, int own_off, const float* bias,
+                          uint16_t* out, int out_cstride, w2c_stream_t stream);
+
+/* ---- Indirect operands (round 4).  The module boundary hands the forward a caller-owned input tensor and returns caller-owned
+ * output tensors (SURVEY 8b "Ownership"), so the first and the last kernel of a forward touch addresses that change from call to
+ * call -- which kept them outside the captured HIP graph (two eager launches + two graph boundaries per forward).  The pointer
+ * arguments marked [indirect-capable] below accept, instead of the address itself, the address of a DEVICE-RESIDENT 8-byte POINTER
+ * SLOT with bit 0 set:  arg = (uintptr_t)slot | 1.  The kernel reads the slot when it starts.  w2c_set_slots writes up to 8 slots in
+ * stream order -- the values travel as kernel arguments, so the host may run any number of forwards ahead -- and the whole forward,
+ * stem to upsample, replays from ONE graph.  [indirect-capable]: `x` / `frames` of w2c_stem_conv7x7_bn_relu_maxpool and
+ * w2c_stem_u8_conv7x7_bn_relu_maxpool, `out` of w2c_upsample_bilinear32, `labels` / `gt` / `hist` of w2c_upsample32_argmax[_confusion],
+ * `dst` of w2c_copy_to_slot.  The target of a slot must satisfy the alignment the direct form requires. */
+int w2c_set_slots(void* slots, int n, const void* const* values, w2c_stream_t stream);
+/* dst[0 .. nbytes) = src[0 .. nbytes) (nbytes % 4 == 0; dst [indirect-capable]): the packed prob / action / nnz of a captured
+ * forward into the caller-owned copy. */
+int w2c_copy_to_slot(const void* src, long long nbytes, void* dst, w2c_stream_t stream);
+
 /* ---- K9: bilinear x32 upsample, align_corners=False (backbone.py:160).
  * low : f32 NHWC [M, h, w, low_cstride] (first n_classes channels used)
  * out : f32 NCHW [M, n_classes, 32h, 32w] */

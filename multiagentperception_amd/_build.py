@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
 # kernels contains a v_pk_{fma,mul,add}_f32.  (The conv kernels' epilogues do contain v_pk_fma_f32 -- from explicit
 # float4 arithmetic -- and are bit-stable beside MFMA waves in every torch.equal test, so the hazard is specific to these kernels'
 # packed form, not a blanket rule; tools/ubench/pkfma_mfma.hip is the stand-alone probe.)
-PACKED_F32_FREE = ("linear_widek_kernel", "linear_kernel", "head_tail", "comm_graph_kernel", "graph_fuse_kernel", "fuse_kernel",
+PACKED_F32_FREE = ("linear_widek_kernel", "linear_kernel", "head_tail", "head_fc0_mfma_kernel", "comm_graph_kernel", "graph_fuse_kernel", "fuse_kernel",
                    "key_project_kernel")
 
 

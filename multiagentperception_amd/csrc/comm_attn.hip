@@ -166,16 +166,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // K-MAJOR ([K][O]) so consecutive threads read consecutive outputs of one k (coalesced, L2-resident).
 // Latency-bound by construction (tiny), so every loop keeps 16 independent loads in flight; each slice
 // recomputes the 128-wide hidden layer (32 K MACs) rather than synchronising through memory.
+// n_part > 0: h0 is not the finished fc.0 output but n_part split-K partial sums of it (w2c_head_fc0_mfma_f32), part_stride floats
+// apart: h0[k] = relu(sum_p part_p[k] + b0[k]), summed in part order (deterministic).
 __device__ __forceinline__ void head_tail_body(const float* __restrict__ h0, int h0_stride, int K1,
                                                const float* __restrict__ w1t, const float* __restrict__ b1, int H1,
                                                const float* __restrict__ w2t, const float* __restrict__ b2, int O,
-                                               float* __restrict__ out) {
+                                               float* __restrict__ out, int n_part = 0, long part_stride = 0,
+                                               const float* __restrict__ b0 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_h0 = reinterpret_cast<float*>(smem);          // [K1]
     float* s_h1 = s_h0 + K1;                               // [H1]
     float* s_part = s_h1 + H1;                             // [256]
     const int m = blockIdx.x, tid = threadIdx.x;
-    for (int k = tid; k < K1; k += 256) s_h0[k] = h0[(size_t)m * h0_stride + k];
+    if (n_part > 0) {
+        for (int k = tid; k < K1; k += 256) {
+            const float* src = h0 + (size_t)m * h0_stride + k;
+            float v = 0.f;
+            int pp = 0;
+            for (; pp + 8 <= n_part; pp += 8) {                        // 8 partials in flight, added in part order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(pp + u) * part_stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; pp < n_part; ++pp) v += src[(size_t)pp * part_stride];
+            s_h0[k] = fmaxf(v + b0[k], 0.f);
+        }
+    } else {
+        for (int k = tid; k < K1; k += 256) s_h0[k] = h0[(size_t)m * h0_stride + k];
+    }
     __syncthreads();
     // layer 1: thread = (output j, K-partition)
     const int parts = 256 / H1;                            // H1 <= 256
@@ -244,10 +264,81 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
 // both heads (key and query tails read disjoint column ranges of the same fc.0 output) in ONE launch: blockIdx.z = head.
 struct HeadTailSet { const float* w1t; const float* b1; const float* w2t; const float* b2; float* out; int col_off; int O; };
 __global__ __launch_bounds__(256) void head_tail2_kernel(const float* __restrict__ h0, int h0_stride, int K1, int H1,
-                                                         HeadTailSet a, HeadTailSet b) {
+                                                         HeadTailSet a, HeadTailSet b, int n_part, long part_stride,
+                                                         const float* __restrict__ b0) {
     const HeadTailSet& s = blockIdx.z == 0 ? a : b;
     if ((int)blockIdx.y * 256 >= s.O) return;              // the narrower head has fewer 256-output slices (whole workgroup)
-    head_tail_body(h0 + s.col_off, h0_stride, K1, s.w1t, s.b1, H1, s.w2t, s.b2, s.O, s.out);
+    head_tail_body(h0 + s.col_off, h0_stride, K1, s.w1t, s.b1, H1, s.w2t, s.b2, s.O, s.out, n_part, part_stride,
+                   b0 ? b0 + s.col_off : nullptr);
+}
+
+// ---------------------------------------------------------------- K5, round 4: fc.0 of the heads on the f32 matrix pipe
+// y[m][o] = sum_k x[m][k] W[o][k]  (M = 20 .. 128 rows, K = 4096, O = 512: 84 MFLOP, 8 MB of f32 weights).  The VALU form above
+// (linear_widek_kernel: one workgroup per output column, every workgroup re-reads all M rows of x) took 25-28 us at the END of the
+// policy chain, the forward's critical path.  v_mfma_f32_32x32x2_f32 is exact f32 (an fmaf chain per output, MI355X_MICROARCH.md) at the
+// f32 vector rate, which is plenty here: the kernel is bound by streaming the weights once.
+//   grid = (O / 32 column tiles, KS K-splits); workgroup = 4 waves, wave w takes the 64-deep K slice [ks * 256 + 64 w, +64);
+//   weights arrive FRAGMENT-PACKED (HeadPlan): block (column tile, 8 k) = 64 lanes x 16 B, lane (o % 32, half) holds
+//   W[o][8 q + 4 half + 0..3]: one coalesced 1 KB load feeds 4 MFMAs; x: lane (row % 32, half) loads the 4 bf16 at the same k;
+//   MFMA e of a block contracts k in {8 q + e, 8 q + 4 + e} -- the same pairing for both operands, which is all a dot product needs;
+//   the 4 waves' partial tiles meet in LDS, are added in wave order and stored as ONE partial per (K-split, row, column):
+//   part[ks][m][o].  The tail kernel adds the KS partials in order (+ bias, ReLU).  Deterministic; independent of M (an output's
+//   sum order is fixed by (ks, wave, q, e)), so a rank's shard rounds like the unsharded batch.
+template <int RB>                                          // 32-row blocks of x (M <= 32 RB)
+__global__ __launch_bounds__(256) void head_fc0_mfma_kernel(const uint16_t* __restrict__ x, int x_stride, int M, int K,
+                                                            const float* __restrict__ wf, int O, float* __restrict__ part) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float red[4][RB][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int ot = blockIdx.x, ks = blockIdx.y, KS = gridDim.y;
+    const int kw = K / KS / 4;                               // K slice of a wave (multiple of 8)
+    const int k0 = ks * (K / KS) + wave * kw;
+    const int nq = kw >> 3;
+    const f32x4_t* wp = reinterpret_cast<const f32x4_t*>(wf) + ((size_t)ot * (K >> 3) + (k0 >> 3)) * 64 + lane;
+    const uint16_t* xp[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int m = rb * 32 + l31 < M ? rb * 32 + l31 : M - 1;          // clamp: rows past M are computed and dropped
+        xp[rb] = x + (size_t)m * x_stride + k0 + 4 * lhi;
+    }
+    f32x16_t acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+    for (int q = 0; q < nq; q += 4) {                        // 4 blocks (32 k) of loads in flight
+        f32x4_t wv[4];
+        uint2 xv[4][RB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wv[u] = wp[(size_t)(q + u) * 64];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) xv[u][rb] = *reinterpret_cast<const uint2*>(xp[rb] + (q + u) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float xe[4] = {__uint_as_float(xv[u][rb].x << 16), __uint_as_float(xv[u][rb].x & 0xFFFF0000u),
+                                     __uint_as_float(xv[u][rb].y << 16), __uint_as_float(xv[u][rb].y & 0xFFFF0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][e], xe[e], acc[rb], 0, 0, 0);
+            }
+    }
+    // D layout: lane = row l31 of the block, element r = column (r & 3) + 8 (r >> 2) + 4 lhi of the tile
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][rb][r][lane] = acc[rb][r];
+    __syncthreads();
+    for (int i = tid; i < RB * 16 * 64; i += 256) {
+        const int ln = i & 63, r = (i >> 6) & 15, rb = i >> 10;
+        const float v = ((red[0][rb][r][ln] + red[1][rb][r][ln]) + red[2][rb][r][ln]) + red[3][rb][r][ln];
+        const int m = rb * 32 + (ln & 31), o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        if (m < M) part[((size_t)ks * M + m) * O + o] = v;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- K6: communication graph
@@ -541,6 +632,111 @@ __global__ __launch_bounds__(256) void graph_fuse_kernel(const float* __restrict
     }
 }
 
+// K6 + K7 + the decoder's first conv by LINEARITY (round 4).  conv0 of the decoder (backbone.py:150-152: conv3x3 + bias, then ReLU) is
+// linear before its bias, and the fused map is a linear combination of the agents' value maps (agent.py:276-284), so
+//     conv0(sum_k P[k,q] V[k]) = sum_k P[k,q] U[k],   U[k] = conv0_nobias(V[k])
+// (MIMOcomWho, decoder input cat(fused, V[q]), agent.py:1382: + U_own[q], the conv of V[q] with the second half of the filters).
+// The U maps (f32) depend on the value encoder alone and are computed while the policy chain -- the critical path -- is still
+// running; after the join only this kernel is left in front of the decoder's last conv: graph column(s) as in graph_fuse_kernel, then
+//     y[q] = relu(sum_k coef[k,q] U[k] (+ U_own[q]) + bias)  -> bf16.
+// The weighted sum runs in f32 over f32 maps and is rounded ONCE (the V-fusing form rounds the fused map to bf16 before the conv).
+// thread = 4 channels (16 B of f32) of one (b, pixel): every key's 16 bytes are loaded once and reused by all queries.
+__global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restrict__ query, const float* __restrict__ T,
+                                                           int B, int N, int Dq, int who, int mode, float thres, float tie_bias,
+                                                           int q_lo, int q_n, float* __restrict__ prob, float* __restrict__ coef,
+                                                           int64_t* __restrict__ action, int32_t* __restrict__ nnz,
+                                                           const float* __restrict__ u, int ucs, int hw, int C, int own_off,
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ out, int ocs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cs = reinterpret_cast<float*>(smem);          // [N][q_n] for this b, then one int
+    int* cnt = reinterpret_cast<int*>(cs + N * q_n);
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool writer = blockIdx.x == 0;
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    int local_nnz = 0;
+    for (int ql = wave; ql < q_n; ql += 4) {
+        float pr, cf;
+        int act;
+        if (graph_column(query, T, B, N, Dq, who, mode, thres, tie_bias, b, q_lo + ql, ql, lane, pr, cf, act)) ++local_nnz;
+        if (lane < N) {
+            cs[lane * q_n + ql] = cf;
+            if (writer) {
+                const size_t o = ((size_t)b * N + lane) * q_n + ql;
+                prob[o] = pr;
+                coef[o] = cf;
+            }
+        }
+        if (writer && lane == 0) action[(size_t)b * q_n + ql] = act;
+    }
+    if (writer) {
+        local_nnz = (int)wave_sum((float)local_nnz);
+        if (lane == 0 && local_nnz) atomicAdd(cnt, local_nnz);
+    }
+    __syncthreads();
+    if (writer && tid == 0) nnz[b] = *cnt;
+    const int CG = C >> 2;
+    const int total = hw * CG;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int px = id / CG, cg = id - px * CG;
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + cg * 4);
+        if (N <= 8) {
+            // small graphs (cfg 2: 5 agents): all keys' 16 bytes in flight together; a key no query uses is not loaded (wave-uniform)
+            f32x4_t uk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bool used = false;
+                if (k < N)
+                    for (int ql = 0; ql < q_n; ++ql) used |= cs[k * q_n + ql] != 0.f;
+                uk[k] = used ? *reinterpret_cast<const f32x4_t*>(u + ((size_t)(k * B + b) * hw + px) * ucs + cg * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int ql = 0; ql < q_n; ++ql) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k >= N) break;
+                    const float c = cs[k * q_n + ql];
+                    if (c == 0.f) continue;                           // same skip as the general loop: same fmaf sequence, same bits
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(c, uk[k][e], acc[e]);
+                }
+                if (own_off >= 0) {
+                    const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(u + ((size_t)((q_lo + ql) * B + b) * hw + px) * ucs + own_off + cg * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += o4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] + bv[e], 0.f);
+                uint2 o;
+                o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+                *reinterpret_cast<uint2*>(out + ((size_t)(ql * B + b) * hw + px) * ocs + cg * 4) = o;
+            }
+            continue;
+        }
+        for (int ql = 0; ql < q_n; ++ql) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < N; ++k) {
+                const float c = cs[k * q_n + ql];
+                if (c == 0.f) continue;
+                const f32x4_t v4 = *reinterpret_cast<const f32x4_t*>(u + ((size_t)(k * B + b) * hw + px) * ucs + cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(c, v4[e], acc[e]);
+            }
+            if (own_off >= 0) {
+                const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(u + ((size_t)((q_lo + ql) * B + b) * hw + px) * ucs + own_off + cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += o4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] + bv[e], 0.f);
+            uint2 o;
+            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+            *reinterpret_cast<uint2*>(out + ((size_t)(ql * B + b) * hw + px) * ocs + cg * 4) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int w2c_linear_f32(const void* x, int x_is_bf16, int x_stride, int M, int K,
@@ -587,7 +783,37 @@ extern "C" int w2c_head_tail2_f32(const float* h0, int h0_stride, int M, int K1,
     const int omax = O_a > O_b ? O_a : O_b;
     HeadTailSet a{w1t_a, b1_a, w2t_a, b2_a, out_a, col_off_a, O_a}, b{w1t_b, b1_b, w2t_b, b2_b, out_b, col_off_b, O_b};
     hipLaunchKernelGGL(head_tail2_kernel, dim3(M, (omax + 255) / 256, 2), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                       h0, h0_stride, K1, H1, a, b);
+                       h0, h0_stride, K1, H1, a, b, 0, 0L, static_cast<const float*>(nullptr));
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_head_fc0_mfma_f32(const uint16_t* x, int x_stride, int M, int K, const float* wfrag, int O, int ksplit,
+                                     float* part, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !wfrag || !part || M <= 0 || M > 64 || K <= 0 || O <= 0 || (O % 32) != 0 || ksplit <= 0) return W2C_E_ARG;
+    if ((K % (ksplit * 128)) != 0 || (x_stride % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(wfrag) & 15))
+        return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M <= 32) hipLaunchKernelGGL((head_fc0_mfma_kernel<1>), dim3(O / 32, ksplit), dim3(256), 0, s, x, x_stride, M, K, wfrag, O, part);
+    else hipLaunchKernelGGL((head_fc0_mfma_kernel<2>), dim3(O / 32, ksplit), dim3(256), 0, s, x, x_stride, M, K, wfrag, O, part);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_head_tail2p_f32(const float* part, int n_part, long long part_stride, const float* b0, int h0_stride, int M, int K1, int H1,
+                                   int col_off_a, const float* w1t_a, const float* b1_a, const float* w2t_a, const float* b2_a, int O_a,
+                                   float* out_a,
+                                   int col_off_b, const float* w1t_b, const float* b1_b, const float* w2t_b, const float* b2_b, int O_b,
+                                   float* out_b, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!part || !b0 || n_part <= 0 || part_stride <= 0) return W2C_E_ARG;
+    if (!w1t_a || !b1_a || !w2t_a || !b2_a || !out_a || !w1t_b || !b1_b || !w2t_b || !b2_b || !out_b) return W2C_E_ARG;
+    if (M <= 0 || K1 <= 0 || H1 <= 0 || H1 > 256 || O_a <= 0 || O_b <= 0 || col_off_a < 0 || col_off_b < 0) return W2C_E_ARG;
+    if (h0_stride < col_off_a + K1 || h0_stride < col_off_b + K1) return W2C_E_ARG;
+    const size_t lds = (size_t)(K1 + H1 + 256) * 4;
+    const int omax = O_a > O_b ? O_a : O_b;
+    HeadTailSet a{w1t_a, b1_a, w2t_a, b2_a, out_a, col_off_a, O_a}, b{w1t_b, b1_b, w2t_b, b2_b, out_b, col_off_b, O_b};
+    hipLaunchKernelGGL(head_tail2_kernel, dim3(M, (omax + 255) / 256, 2), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       part, h0_stride, K1, H1, a, b, n_part, (long)part_stride, b0);
     return w2c_launch_status();
 }
 
@@ -654,5 +880,27 @@ extern "C" int w2c_comm_graph_fuse(const float* query, const float* tproj, int B
     hipLaunchKernelGGL(graph_fuse_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), query, tproj, B, N, Dq,
                        who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag, v, v_cstride, hw, C, append_own,
                        out, out_cstride);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
+                                     float thres, float tie_bias, int q_lo, int q_n,
+                                     float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
+                                     const float* u, int u_cstride, int hw, int C, int own_off, const float* bias,
+                                     uint16_t* out, int out_cstride, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!tproj || !prob || !coef || !action || !nnz_offdiag || !u || !bias || !out) return W2C_E_ARG;
+    if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
+    if (q_lo < 0 || q_n <= 0 || q_lo + q_n > N) return W2C_E_ARG;
+    if (hw <= 0 || C <= 0 || (C % 4) != 0 || (u_cstride % 4) != 0 || (out_cstride % 4) != 0 || u_cstride < C || out_cstride < C) return W2C_E_ARG;
+    if (own_off >= 0 && ((own_off % 4) != 0 || own_off + C > u_cstride)) return W2C_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(u) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return W2C_E_ARG;
+    const int total = hw * (C / 4);
+    int bx = (total + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const size_t lds = (size_t)N * q_n * 4 + 16;
+    hipLaunchKernelGGL(graph_fuse_u_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), query, tproj, B, N, Dq,
+                       who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag, u, u_cstride, hw, C, own_off < 0 ? -1 : own_off,
+                       bias, out, out_cstride);
     return w2c_launch_status();
 }

@@ -192,12 +192,13 @@ __device__ unsigned long long g_stem_phase[8];
 #endif
 
 template <int COUT, bool U8, int BAND, int NW>
-__global__ __launch_bounds__(64 * NW) void stem_pool_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
+__global__ __launch_bounds__(64 * NW) void stem_pool_kernel(const void* xv_arg, FrameMean mean, int B, int N, int H, int W,
                                                         const uint16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         uint16_t* __restrict__ y) {
     constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>(), CR = BAND + 1;   // CR = conv rows per step
+    const void* const __restrict__ xv = w2c_resolve(xv_arg);       // indirect operand: the frames' address may come from a pointer slot
     constexpr int CT = COUT / 32;           // channel tiles
     constexpr int NT = 64 * NW;             // NW = 8 waves, or 12 so that the BAND + 1 = 9 conv rows split 3/3/3 (no 4-vs-5 wait)
     constexpr int NPART = NW / CT;          // conv-row partitions across waves
@@ -398,12 +399,13 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 }
 
 template <int COUT, bool U8>
-__global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) void stem_pool2_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
+__global__ __launch_bounds__(COUT * 2) __attribute__((amdgpu_waves_per_eu(2))) void stem_pool2_kernel(const void* xv_arg, FrameMean mean, int B, int N, int H, int W,
                                                             const uint16_t* __restrict__ wpk,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             uint16_t* __restrict__ y) {
     constexpr int BAND = 8, CR = 9;
+    const void* const __restrict__ xv = w2c_resolve(xv_arg);       // indirect operand: the frames' address may come from a pointer slot
     constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>();
     constexpr int CT = COUT / 32, NT = 64 * CT;
     constexpr int SPX = 80;                                    // staging pitch per pooled pixel: 64 B + 16 (pixel rows 20 banks apart:
@@ -677,11 +679,12 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
 }
 
 template <bool U8>
-__global__ __launch_bounds__(512) void stem_pool3_kernel(const void* __restrict__ xv, FrameMean mean, int B, int N, int H, int W,
+__global__ __launch_bounds__(512) void stem_pool3_kernel(const void* xv_arg, FrameMean mean, int B, int N, int H, int W,
                                                          const uint16_t* __restrict__ wpk, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, uint16_t* __restrict__ y, int steps_per_wg,
                                                          int total_steps) {
     constexpr int COUT = 128, BAND = 8;
+    const void* const __restrict__ xv = w2c_resolve(xv_arg);       // indirect operand: the frames' address may come from a pointer slot
     constexpr int FP_ROWS = fp_rows<BAND>(), FP_BYTES = fp_bytes<BAND>();
     constexpr int CT = COUT / 32, NT = 64 * CT;                // NT = threads per GROUP
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -20,7 +20,8 @@ __device__ __forceinline__ float lerp2d(float ly0, float ly1, float lx0, float l
 }
 
 __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
-                                                         float* __restrict__ out) {
+                                                         float* out_arg) {
+    float* const __restrict__ out = w2c_resolve(out_arg);       // indirect operand: the logits' address may come from a pointer slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* plane = reinterpret_cast<float*>(smem);     // [h][w]
     const int H = h * 32, W = w * 32;
@@ -65,8 +66,11 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
 constexpr int ARG_ROWS = 8;
 template <bool CONF, bool GT64>
 __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
-                                                                uint8_t* __restrict__ labels, const void* __restrict__ gt,
-                                                                unsigned long long* __restrict__ hist) {
+                                                                uint8_t* labels_arg, const void* gt_arg,
+                                                                unsigned long long* hist_arg) {
+    uint8_t* const __restrict__ labels = w2c_resolve(labels_arg);   // indirect operands (caller-owned tensors of a captured forward)
+    const void* const __restrict__ gt = w2c_resolve(gt_arg);
+    unsigned long long* const __restrict__ hist = w2c_resolve(hist_arg);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* blk = reinterpret_cast<float*>(smem);       // [ncls][h][w]
     unsigned* lh = reinterpret_cast<unsigned*>(smem + (size_t)ncls * h * w * 4);      // CONF: [ncls*ncls] band histogram
@@ -293,7 +297,10 @@ extern "C" int w2c_upsample32_argmax_confusion(const float* low, int M, int h, i
     w2c_clear_error();
     if (!low || !gt || !hist || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || n_classes > 64 || low_cstride < n_classes)
         return W2C_E_ARG;
-    if ((reinterpret_cast<uintptr_t>(gt) & (gt_is_i64 ? 7 : 3)) || (reinterpret_cast<uintptr_t>(hist) & 7)) return W2C_E_ARG;
+    // (a tagged pointer -- bit 0 set: the address of a pointer slot -- is resolved on the device; its target's alignment is the caller's to keep)
+    if ((!(reinterpret_cast<uintptr_t>(gt) & 1) && (reinterpret_cast<uintptr_t>(gt) & (gt_is_i64 ? 7 : 3))) ||
+        (!(reinterpret_cast<uintptr_t>(hist) & 1) && (reinterpret_cast<uintptr_t>(hist) & 7)))
+        return W2C_E_ARG;
     const size_t lds = (size_t)n_classes * h * w * 4 + (size_t)n_classes * n_classes * 4;
     if (lds > 64 * 1024) return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -339,6 +346,37 @@ extern "C" int w2c_nhwc_bf16_to_nchw_f32(const uint16_t* x, int x_cstride, int M
     const size_t total = (size_t)M * C * H * W;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        x, x_cstride, M, C, H * W, y);
+    return w2c_launch_status();
+}
+
+namespace {
+struct SlotValues { const void* v[8]; };
+__global__ void set_slots_kernel(const void** slots, int n, SlotValues vals) {
+    if ((int)threadIdx.x < n) slots[threadIdx.x] = vals.v[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void copy_to_slot_kernel(const uint32_t* __restrict__ src, long long n_words, uint32_t* dst_arg) {
+    uint32_t* const __restrict__ dst = w2c_resolve(dst_arg);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
+// Indirect operands, host side: fill up to 8 device-resident pointer slots in stream order (the values travel as kernel arguments, so
+// the host may run any number of forwards ahead), and copy a small buffer to the address held in a slot.
+extern "C" int w2c_set_slots(void* slots, int n, const void* const* values, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!slots || !values || n <= 0 || n > 8 || (reinterpret_cast<uintptr_t>(slots) & 7)) return W2C_E_ARG;
+    SlotValues v{};
+    for (int i = 0; i < n; ++i) v.v[i] = values[i];
+    hipLaunchKernelGGL(set_slots_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const void**>(slots), n, v);
+    return w2c_launch_status();
+}
+extern "C" int w2c_copy_to_slot(const void* src, long long nbytes, void* dst, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!src || !dst || nbytes <= 0 || (nbytes & 3) || (reinterpret_cast<uintptr_t>(src) & 3)) return W2C_E_ARG;
+    const long long nw = nbytes / 4;
+    const unsigned grid = (unsigned)((nw + 255) / 256 > 64 ? 64 : (nw + 255) / 256);
+    hipLaunchKernelGGL(copy_to_slot_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint32_t*>(src), nw, reinterpret_cast<uint32_t*>(dst));
     return w2c_launch_status();
 }
 

@@ -46,6 +46,18 @@ __device__ __forceinline__ i32x8_t cat_i32x8(u32x4_t lo, u32x4_t hi) {
     return i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 }
 
+// Indirect operands (include/w2c_hip.h "indirect operands"): a pointer argument with bit 0 set is the address (| 1) of a device-resident
+// 8-byte slot that holds the real pointer; the kernel reads the slot when it starts.  A captured HIP graph can then run on a different
+// caller-owned tensor at every replay (w2c_set_slots fills the slots in stream order just before the replay) without copying the
+// tensor into a static buffer and without re-capturing.  Wave-uniform: one scalar load + branch.
+#define W2C_UNTAG(p) (reinterpret_cast<uintptr_t>(p) & ~static_cast<uintptr_t>(1))
+template <typename T>
+__device__ __forceinline__ T* w2c_resolve(T* p) {
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    if (v & 1) return *reinterpret_cast<T* const*>(v & ~static_cast<uintptr_t>(1));
+    return p;
+}
+
 // Last HIP error text of the calling thread (for w2c_last_error_string()).
 inline char* w2c_errbuf() {
     static thread_local char buf[256] = {0};

@@ -39,6 +39,52 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+class SlotRef:
+    """Stand-in for a caller-owned tensor whose ADDRESS a kernel reads from a device-resident pointer slot when it starts
+    (include/w2c_hip.h "indirect operands": the argument is the slot's address with bit 0 set).  Carries the shape / dtype / device the
+    wrappers check; `like` is a tensor (or SlotRef) of the geometry every later target will have."""
+    is_cuda = True
+
+    def __init__(self, slots, index, like):
+        if slots.dtype != torch.int64 or not slots.is_cuda or index < 0 or index >= slots.numel():
+            raise W2CError("SlotRef: slots must be an int64 device tensor and index inside it")
+        self.slots, self.index = slots, index
+        self.shape, self.dtype, self.device = tuple(like.shape), like.dtype, slots.device
+
+    def data_ptr(self):
+        return (self.slots.data_ptr() + 8 * self.index) | 1
+
+    def dim(self):
+        return len(self.shape)
+
+    def numel(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    def is_contiguous(self):
+        return True
+
+
+def set_slots(slots, tensors):
+    """w2c_set_slots: slots[i] = address of tensors[i] (None -> 0), in stream order on the current stream."""
+    import ctypes
+    dev = slots.device
+    n = len(tensors)
+    vals = (ctypes.c_void_p * n)(*[(_p(t) or None) for t in tensors])
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_set_slots(_p(slots), n, ctypes.cast(vals, ctypes.c_void_p), _stream(dev)), "w2c_set_slots")
+
+
+def copy_to_slot(src, dst):
+    """w2c_copy_to_slot: src (contiguous device tensor, nbytes % 4 == 0) -> dst (tensor of the same byte size, or a SlotRef)."""
+    dev = _need_gpu(src)
+    nbytes = src.numel() * src.element_size()
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_copy_to_slot(_p(src), nbytes, _p(dst), _stream(dev)), "w2c_copy_to_slot")
+
+
 class KernelTimer:
     """Opt-in per-launch timing of the dominant kernel (w2c_conv_igemm_bf16) with HIP events on
     the launch stream (torch.cuda.Event on torch's current stream == the stream we launch on).
@@ -785,6 +831,58 @@ def head_tail2(h0, k1, tail_a, tail_b, out_a=None, out_b=None):
     return out_a, out_b
 
 
+def pack_fc0_frag(w0):
+    """[O, K] f32 fc.0 weights (heads stacked along O) -> the fragment order of w2c_head_fc0_mfma_f32 (include/w2c_hip.h):
+    [O/32][K/8][half][o % 32][4].  Same values, permuted; host or device tensor."""
+    O, K = w0.shape
+    if O % 32 or K % 8:
+        raise W2CError("pack_fc0_frag: O % 32 == 0 and K % 8 == 0 required")
+    return w0.reshape(O // 32, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(O, K)
+
+
+HEAD_FC0_KSPLIT = 16
+
+
+def head_fc0_supported(M, K, O, ksplit=HEAD_FC0_KSPLIT):
+    return M <= 64 and O % 32 == 0 and K % (ksplit * 128) == 0
+
+
+def head_fc0_mfma(x, x_stride, M, K, wfrag, O, ksplit=HEAD_FC0_KSPLIT, part=None):
+    """fc.0 of the heads on the f32 matrix pipe: x bf16 rows [M][x_stride] -> split-K partials f32 [ksplit, M, O] (no bias, no ReLU)."""
+    dev = _need_gpu(x, wfrag, part)
+    if x.dtype != BF16 or wfrag.dtype != torch.float32:
+        raise W2CError("head_fc0_mfma: x must be bf16, wfrag f32")
+    if part is None:
+        part = torch.empty((ksplit, M, O), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_head_fc0_mfma_f32(_p(x), x_stride, M, K, _p(wfrag), O, ksplit, _p(part), _stream(dev)),
+              "w2c_head_fc0_mfma_f32")
+    return part
+
+
+def head_tail2_parts(part, b0, k1, tail_a, tail_b, out_a=None, out_b=None):
+    """head_tail2 on split-K partials of fc.0 (part f32 [P, M, O_total]): h0 = relu(sum_p part[p] + b0) in the same launch."""
+    ca, w1a, b1a, w2a, b2a = tail_a
+    cb, w1b, b1b, w2b, b2b = tail_b
+    dev = _need_gpu(part, b0, w1a, b1a, w2a, b2a, w1b, b1b, w2b, b2b)
+    P, M, stride = part.shape
+    H1 = w1a.shape[1]
+    if w1b.shape[1] != H1 or min(ca, cb) < 0 or max(ca, cb) + k1 > stride or w1a.shape[0] != k1 or w1b.shape[0] != k1:
+        raise W2CError("head_tail2_parts: column ranges / weights do not fit %s" % (tuple(part.shape),))
+    if out_a is None:
+        out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
+    if out_b is None:
+        out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
+    for o, w2 in ((out_a, w2a), (out_b, w2b)):
+        if tuple(o.shape) != (M, w2.shape[1]) or o.dtype != torch.float32 or not o.is_contiguous() or o.device != dev:
+            raise W2CError("head_tail2_parts: bad preallocated output %s" % (tuple(o.shape),))
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_head_tail2p_f32(_p(part), P, M * stride, _p(b0), stride, M, k1, H1, ca, _p(w1a), _p(b1a), _p(w2a),
+                                                _p(b2a), w2a.shape[1], _p(out_a), cb, _p(w1b), _p(b1b), _p(w2b), _p(b2b),
+                                                w2b.shape[1], _p(out_b), _stream(dev)), "w2c_head_tail2p_f32")
+    return out_a, out_b
+
+
 MODE_IDS = {"softmax": 0, "argmax_test": 1, "activated": 2}
 
 
@@ -860,6 +958,27 @@ def comm_graph_fuse(query, tproj, v, v_ch, B, N, who, mode, thres=0.2, tie_bias=
                                                 float(tie_bias), q_lo, q_n, _p(prob), _p(coef), _p(action), _p(nnz), _p(v), vcs,
                                                 h * w, v_ch, 1 if append_own else 0, _p(out), ocs, _stream(dev)),
               "w2c_comm_graph_fuse")
+    return out, prob, coef, action, nnz, pack
+
+
+def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None, own_off=-1):
+    """w2c_comm_graph_fuse_u: graph + fusion of the U maps (decoder conv0 of every agent's value map, no bias, f32 NHWC
+    [N*B,h,w,ucs]) + bias + ReLU -> y bf16 [q_n*B,h,w,C] = relu(conv0(fused map)), prob, coef, action, nnz, pack."""
+    dev = _need_gpu(query, tproj, u, bias)
+    Dq = tproj.shape[1] - 1
+    if q_n is None:
+        q_n = N - q_lo
+    if u.dtype != torch.float32 or bias.dtype != torch.float32 or bias.numel() != C:
+        raise W2CError("comm_graph_fuse_u: u and bias must be f32, bias [C]")
+    pack, prob, action, nnz = graph_outputs(dev, B, N, q_n)
+    coef = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
+    _, h, w, ucs = u.shape
+    out = torch.empty((q_n * B, h, w, C), dtype=BF16, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_comm_graph_fuse_u(_p(query), _p(tproj), B, N, Dq, 1 if who else 0, MODE_IDS[mode], float(thres),
+                                                  float(tie_bias), q_lo, q_n, _p(prob), _p(coef), _p(action), _p(nnz), _p(u), ucs,
+                                                  h * w, C, int(own_off), _p(bias), _p(out), C, _stream(dev)),
+              "w2c_comm_graph_fuse_u")
     return out, prob, coef, action, nnz, pack
 
 
@@ -945,11 +1064,12 @@ def cross_entropy2d_backward(logits, target, weight, lse, denom=None, gout=None,
     return d
 
 
-def upsample32_argmax(low, n_classes):
-    """low f32 NHWC [M,h,w,lcs] -> u8 labels [M,32h,32w] = argmax_c of the bilinear x32 upsample."""
+def upsample32_argmax(low, n_classes, out=None):
+    """low f32 NHWC [M,h,w,lcs] -> u8 labels [M,32h,32w] = argmax_c of the bilinear x32 upsample (out: tensor or SlotRef)."""
     dev = _need_gpu(low)
     M, h, w, lcs = low.shape
-    out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_upsample32_argmax(_p(low), M, h, w, lcs, n_classes, _p(out), _stream(dev)),
               "w2c_upsample32_argmax")
@@ -964,16 +1084,17 @@ def _gt_kind(gt):
     raise W2CError("ground-truth labels must be uint8 or int64, got %s" % gt.dtype)
 
 
-def upsample32_argmax_confusion(low, n_classes, gt, hist, want_labels=False):
+def upsample32_argmax_confusion(low, n_classes, gt, hist, want_labels=False, out=None):
     """K9 + class argmax + confusion matrix (metrics.py:99-108) in one launch.  gt: u8 or i64 [M,32h,32w];
-    hist: int64 [n*n] accumulated in place.  Returns the u8 label map when want_labels, else None."""
+    hist: int64 [n*n] accumulated in place.  Returns the u8 label map when want_labels, else None.  (gt / hist / out may be SlotRefs.)"""
     dev = _need_gpu(low, gt, hist)
     M, h, w, lcs = low.shape
     if tuple(gt.shape) != (M, 32 * h, 32 * w):
         raise W2CError("confusion: labels %s do not match the %s prediction map" % (tuple(gt.shape), (M, 32 * h, 32 * w)))
     if hist.dtype != torch.int64 or hist.numel() != n_classes * n_classes:
         raise W2CError("confusion: hist must be int64 [%d]" % (n_classes * n_classes))
-    out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev) if want_labels else None
+    if out is None:
+        out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev) if want_labels else None
     with torch.cuda.device(dev):
         check(_native.lib().w2c_upsample32_argmax_confusion(_p(low), M, h, w, lcs, n_classes, _p(gt), _gt_kind(gt), _p(out),
                                                             _p(hist), _stream(dev)), "w2c_upsample32_argmax_confusion")

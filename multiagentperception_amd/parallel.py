@@ -123,7 +123,13 @@ class _ShardState:
         bf16 = torch.bfloat16
         self.B, self.N, self.n_loc, self.q_lo = B, N, n_loc, q_lo
         self.s0 = torch.empty((n_loc * B, H // 4, W // 4, 64 * eng.trunk.G), dtype=bf16, device=dev)   # pooled stem output
-        self.v_all = torch.zeros((N * B, h, w, eng.feat), dtype=bf16, device=dev)       # every agent's value map
+        # What crosses the wire per agent-sample is U = the decoder's first conv of the value map (f32, 256 channels: the same 1 KiB
+        # per pixel as the bf16 512-channel V it replaces; engine.DecoderPlan.value_maps -- conv0 is linear before its bias, and so is
+        # the fusion).  MIMOcomWho: [U | U_own], 2 KiB per pixel (only the first half is used by the peers).
+        d = eng.decoder
+        ucs = d.c_hidden * (2 if d.own_off >= 0 else 1)
+        self.v_loc = torch.empty((n_loc * B, h, w, eng.feat), dtype=bf16, device=dev)   # local value maps (the value trunk's squeezer)
+        self.v_all = torch.zeros((N * B, h, w, ucs), dtype=torch.float32, device=dev)   # every agent's U map
         self.pol = torch.empty((n_loc * B, h, w, eng.feat), dtype=bf16, device=dev)     # local policy-encoder map
         dq = eng.wq.shape[1]
         self.k_all = torch.zeros((N * B, dq + 1), dtype=torch.float32, device=dev)      # projected keys of every agent
@@ -169,8 +175,9 @@ class AgentParallelForward:
     for the local query agents; N = global agent count.
 
     Per step and rank ('softmax'): stem (eager: reads the caller's tensor) -> segment A: layer1..4 + both squeezers + policy
-    conv1..5 (on the policy chain's stream), the value trunk's squeezer writing V straight into this rank's rows of the
-    all-gather buffer -> async all-gather of V (in place, RCCL) -> segment B: the key / query heads, the projected keys written into this rank's rows of the key
+    conv1..5 (on the policy chain's stream) + the decoder's first conv on the local value maps (on the value chain's stream,
+    by linearity: engine.DecoderPlan.value_maps), writing U straight into this rank's rows of the
+    all-gather buffer -> async all-gather of U (in place, RCCL) -> segment B: the key / query heads, the projected keys written into this rank's rows of the key
     buffer (runs while V is on the wire) -> all-gather of K -> segment C: graph columns of the local queries, fusion,
     decoder convs -> upsample (eager: caller-owned output).  With model.use_hip_graph the three segments are replayed
     from captured HIP graphs (~45 launches -> 3); the collectives stay eager between them."""
@@ -229,8 +236,8 @@ class AgentParallelForward:
         return pred, prob, action, nnz
 
     def encode_local(self, eng, x, use_graph=False):
-        """stem + segment A on this rank's frames: V of the local agents lands in st.v_slot (= their rows of st.v_all),
-        the policy-encoder map in st.pol.  Returns the shard state."""
+        """stem + segment A on this rank's frames: the U maps of the local agents (decoder conv0 of their value maps) land in
+        st.v_slot (= their rows of st.v_all), the policy-encoder map in st.pol.  Returns the shard state."""
         st = self._state(eng, x)
         eng.trunk.stem(x, self.n_loc, out=st.s0)
         if eng.trunk.n8 and eng.trunk.fp8 is None:
@@ -242,13 +249,15 @@ class AgentParallelForward:
                 return amax
             eng.trunk.calibrate(st.s0, reduce_amax=_max_over_ranks)
         if eng.trunk.n8:
-            st.run("A", lambda: tuple(eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol])), use_graph)
+            st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol],
+                                                      value_next=lambda v: eng.value_maps(v, out=st.v_slot))[2],), use_graph)
             st.pol_y = None
         else:
             # as in the one-GPU forward, policy conv1..5 ride the policy chain's stream beside the value chain (they were the whole of
             # the sharded path's extra 0.09 ms per step when segment B ran them after the join); segment B keeps the heads
-            a = st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_slot, st.pol],
-                                                          policy_next=(lambda pol: eng.policy_convs(pol, ch_off=0), lambda y: y))[1],),
+            a = st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol],
+                                                          policy_next=(lambda pol: eng.policy_convs(pol, ch_off=0, gate=True), lambda y: y),
+                                                          value_next=lambda v: eng.value_maps(v, out=st.v_slot))[1],),
                        use_graph)
             st.pol_y = a[0]
         return st

@@ -243,16 +243,18 @@ def test_sparse_handshake_path_equals_dense_forward(mode):
         assert torch.equal(pred, ref[0]) and torch.equal(prob, ref[1]) and torch.equal(action, ref[2])
         assert fwd.last_exchange == (0, 0)
         sq = eng.trunk.run(x, n)
-        assert torch.equal(sq[..., :eng.feat], st.v_all) and torch.equal(sq[..., eng.feat:], st.pol)   # split squeezer output
+        assert torch.equal(sq[..., :eng.feat], st.v_loc) and torch.equal(sq[..., eng.feat:], st.pol)   # split squeezer output
+        u = eng.value_maps(sq)                                            # what crosses the wire: decoder conv0 of every value map
+        assert torch.equal(u, st.v_all)
         keys, querys = eng.policy_tail(sq)
         _, coef, _, _ = ops.comm_graph_projected(querys, keys, b, n, eng.who, mode)
         used = (coef != 0).any(dim=2)                                    # [B, N_keys]
-        v = sq[..., :eng.feat].contiguous()
+        u = u.clone()
         for k in range(n):
             for bb in range(b):
                 if not bool(used[bb, k]):
-                    v[k * b + bb].zero_()
-        pred2, prob2, _, _, _ = eng.graph_and_decode(v, keys, querys, b, n, 0, n, mode)
+                    u[k * b + bb].zero_()
+        pred2, prob2, _, _, _ = eng.graph_and_decode(u, keys, querys, b, n, 0, n, mode)
         assert torch.equal(pred2, ref[0]) and torch.equal(prob2, ref[1])
 
 

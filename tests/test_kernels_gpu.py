@@ -280,6 +280,43 @@ def test_layer1_kernel_forms_are_bit_identical_with_residual_and_relu():
             assert torch.equal(a, c) and torch.equal(b, a), (res is not None, relu)
 
 
+@pytest.mark.parametrize("M", [1, 20, 32, 33, 64])
+def test_head_fc0_on_the_f32_matrix_pipe_matches_fp64_and_is_row_count_independent(M):
+    """w2c_head_fc0_mfma_f32 (+ the split-K sum of w2c_head_tail2p_f32): fc.0 of both heads as v_mfma_f32_32x32x2_f32 over
+    fragment-packed f32 weights.  The MFMA is exact f32, so the only difference from an f64 evaluation is f32 summation order
+    (K = 4096: 2e-5 relative); a row's result does not depend on how many rows are computed with it (sharded == unsharded)."""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(900 + M)
+    K, O, H1 = 4096, 512, 128
+    x = torch.randn(M, K, generator=gen).to(BF16)
+    w0 = torch.randn(O, K, generator=gen) * 0.02
+    b0 = torch.randn(O, generator=gen) * 0.1
+    part = ops.head_fc0_mfma(x.to(_dev()), K, M, K, ops.pack_fc0_frag(w0).to(_dev()), O)
+    assert part.shape == (ops.HEAD_FC0_KSPLIT, M, O)
+    got = part.double().sum(0).cpu()
+    ref = x.double() @ w0.double().t()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+    if M > 1:                                                            # row 0 alone == row 0 inside the batch, bit for bit
+        one = ops.head_fc0_mfma(x[:1].contiguous().to(_dev()), K, 1, K, ops.pack_fc0_frag(w0).to(_dev()), O)
+        assert torch.equal(one[:, 0], part[:, 0])
+    # the tail launch on the partials == the tail launch on the finished fc.0 output it forms from them
+    tails = []
+    for h in range(2):
+        w1 = torch.randn(H1, 256, generator=gen) * 0.05
+        b1 = torch.randn(H1, generator=gen) * 0.1
+        w2 = torch.randn(33 if h == 0 else 32, H1, generator=gen) * 0.05
+        b2 = torch.randn(w2.shape[0], generator=gen) * 0.1
+        tails.append((256 * h, w1.t().contiguous().to(_dev()), b1.to(_dev()), w2.t().contiguous().to(_dev()), b2.to(_dev())))
+    oa, ob = ops.head_tail2_parts(part, b0.to(_dev()), 256, tails[0], tails[1])
+    h0 = part[0].clone()
+    for p_ in range(1, part.shape[0]):
+        h0 += part[p_]
+    h0 = torch.relu(h0 + b0.to(_dev()))
+    ra, rb = ops.head_tail2(h0, 256, tails[0], tails[1])
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ra) and torch.equal(ob, rb)
+
+
 @pytest.mark.parametrize("M,G,H,W,wgs,form", [(6, 2, 64, 64, 0, 0), (3, 1, 32, 48, 0, 0), (5, 2, 40, 32, 7, 0), (2, 2, 128, 128, 0, 0),
                                               (1, 1, 8, 16, 0, 0), (20, 2, 32, 32, 37, 0), (5, 2, 40, 32, 7, 7), (6, 2, 64, 64, 0, 1),
                                               (20, 2, 32, 32, 37, 5)])

@@ -31,3 +31,5 @@ for rep in range(3):
     print("fork %.1f | chain0 (value) head +%.1f blocks %s end +%.1f | chain1 (policy) head +%.1f blocks %s end +%.1f | join +%.1f us" % (
         0.0, t[1] - t0, " ".join("%.0f" % (v - t0) for v in t[8:14]), t[3] - t0,
         t[2] - t0, " ".join("%.0f" % (v - t0) for v in t[16:22]), t[4] - t0, t[5] - t0), flush=True)
+    print("     policy convs end +%.1f | heads end +%.1f | join +%.1f | graph+fuse end +%.1f | decoder convs end +%.1f us" % (
+        t[6] - t0, t[7] - t0, t[5] - t0, t[24] - t0, t[25] - t0), flush=True)
