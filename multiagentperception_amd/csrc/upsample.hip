@@ -56,15 +56,29 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
 
 // K9 + the evaluator's class argmax (trainer.py:804 `outputs.data.max(1)[1]`) fused: the full-resolution f32
 // logits (231 MB at cfg 2) are never written -- only one u8 label per pixel (5 MB).  Same source-index and lerp
-// arithmetic as upsample32_kernel, so labels == argmax over classes of its output, bit for bit; ties keep the
-// lowest class index.  Workgroup = (32-row band, image): the image's whole low-res logit block sits in LDS.
+// arithmetic as upsample32_kernel (lerp2d's three FMAs in its order), so labels == argmax over classes of its output, bit for
+// bit; ties keep the lowest class index.
+//
+// Round 4 form (the first one took 47 us for 5 MB of labels: every workgroup staged the image's whole low-resolution block
+// through LDS with uncoalesced 4-byte reads, and every pixel paid the full 2-D lerp per class).  Now
+//   * thread = 4 consecutive output columns x ARG_ROWS = 8 output rows.  Both share their source cells: x0 changes only at
+//     ox = 16 (mod 32), a multiple of 4, and an 8-row band aligned to 8 never straddles oy = 16 (mod 32) -- so the four corner
+//     pixels are the same for the thread's 32 outputs;
+//   * the corners' class vectors come straight from the NHWC low-resolution map: 4 corners x 3 x 16 B per thread, all in flight
+//     together, L1 / L2 hits (the map is 0.7 MB); no LDS, no barrier;
+//   * lerp2d = vertical lerp of the two HORIZONTAL lerps, and those do not depend on the row: top / bot are formed once per
+//     (class, column) -- 4 operations for 8 rows -- and each output costs one mul + one FMA + the running argmax;
+//   * labels are stored as one dword per row (a wave writes 256 contiguous bytes).
 //
 // CONF: the evaluator's confusion matrix (runningScore._fast_hist, metrics.py:99-108: bincount(n*gt + pred) over the
-// pixels with 0 <= gt < n) fused behind the argmax -- each workgroup histograms its 32-row band in LDS (a wave whose 64
+// pixels with 0 <= gt < n) fused behind the argmax -- each workgroup histograms its pixels in LDS (a wave whose 64
 // lanes all hit one bin, the common case inside a segment, adds 64 with one atomic) and flushes its non-zero bins
 // with one 64-bit global atomic each.  Integer atomics: the result is exact and order-independent.
 constexpr int ARG_ROWS = 8;
-template <bool CONF, bool GT64>
+constexpr int ARG_MAXC = 12;                        // classes handled by the register form (3 x 16 B per corner)
+// MULTI: more than ARG_MAXC classes -- the classes are walked in chunks of ARG_MAXC with the rows' running (best, index) kept across
+// chunks (64 more registers); the comparison order is still class-ascending, so ties keep the lowest index.
+template <bool CONF, bool GT64, bool MULTI = false>
 __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
                                                                 uint8_t* labels_arg, const void* gt_arg,
                                                                 unsigned long long* hist_arg) {
@@ -72,36 +86,27 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
     const void* const __restrict__ gt = w2c_resolve(gt_arg);
     unsigned long long* const __restrict__ hist = w2c_resolve(hist_arg);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* blk = reinterpret_cast<float*>(smem);       // [ncls][h][w]
-    unsigned* lh = reinterpret_cast<unsigned*>(smem + (size_t)ncls * h * w * 4);      // CONF: [ncls*ncls] band histogram
+    unsigned* lh = reinterpret_cast<unsigned*>(smem);      // CONF: [ncls*ncls] workgroup histogram
     if (CONF) {
         for (int i = threadIdx.x; i < ncls * ncls; i += 256) lh[i] = 0;
+        __syncthreads();
     }
     const int H = h * 32, W = w * 32;
-    // a workgroup = ARG_ROWS output rows of one image (32-row bands were 320 workgroups at cfg 2: 1.25 per CU, 4 waves per
-    // CU -- the kernel idled on latency: 46 us for 5 MB of output)
-    const int band = blockIdx.x, m = blockIdx.y;
-    for (int i = threadIdx.x; i < ncls * h * w; i += 256) {
-        const int c = i / (h * w), p = i - c * (h * w);
-        blk[i] = low[((size_t)m * h * w + p) * lcs + c];
-    }
-    __syncthreads();
-    const int xq = W >> 2;
-    uint8_t* obase = labels + ((size_t)m * H + (size_t)band * ARG_ROWS) * W;
-    for (int id = threadIdx.x; id < ARG_ROWS * xq; id += 256) {
-        const int ry = id / xq, gx = id - ry * xq;
-        const int oy = band * ARG_ROWS + ry;
-        float sy = (oy + 0.5f) * 0.03125f - 0.5f;
+    const int xq = W >> 2, nb = H / ARG_ROWS;
+    const int m = blockIdx.y;
+    const int items = nb * xq;                          // (band, column quad) pairs of this image, band-major
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < items; id += gridDim.x * 256) {
+        const int band = id / xq, gx = id - band * xq;
+        // source cells (ATen's area_pixel_compute_source_index, as in upsample32_kernel)
+        float sy = (band * ARG_ROWS + 0.5f) * 0.03125f - 0.5f;
         sy = sy < 0.f ? 0.f : sy;
         const int y0 = (int)sy;
         const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-        // the 4 pixels of a group share their source columns: x0 changes only at ox = 16 (mod 32), a multiple of 4, and the
-        // left-edge clamp (sx < 0 -> 0) covers ox < 16 -- so the four corner values are read once per class, not per pixel
         float sx0 = (gx * 4 + 0.5f) * 0.03125f - 0.5f;
         sx0 = sx0 < 0.f ? 0.f : sx0;
         const int x0 = (int)sx0;
         const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float* lm = low + (size_t)m * h * w * lcs;
         float lx1[4], lx0[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -110,51 +115,123 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
             lx1[e] = sx - (float)x0;
             lx0[e] = 1.f - lx1[e];
         }
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int bi[4] = {0, 0, 0, 0};
-        for (int c = 0; c < ncls; ++c) {
-            const float* pl = blk + c * h * w;
-            const float p00 = pl[y0 * w + x0], p01 = pl[y0 * w + x1], p10 = pl[y1 * w + x0], p11 = pl[y1 * w + x1];
+        float bestr[MULTI ? ARG_ROWS : 1][4];
+        int bir[MULTI ? ARG_ROWS : 1][4];
+        if (MULTI) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = lerp2d(ly0, ly1, lx0[e], lx1[e], p00, p01, p10, p11);
-                if (v > best[e]) { best[e] = v; bi[e] = c; }
-            }
+            for (int ry = 0; ry < ARG_ROWS; ++ry)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bestr[MULTI ? ry : 0][e] = -INFINITY; bir[MULTI ? ry : 0][e] = 0; }
         }
-        const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-        if (labels) *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W + gx * 4) = packed;
+        uint8_t* obase = labels ? labels + ((size_t)m * H + (size_t)band * ARG_ROWS) * W + gx * 4 : nullptr;
+        // CONF: the ground-truth labels of the thread's 8 x 4 pixels, all loads in flight with the corner vectors (read one row at a
+        // time next to their use they were 8 dependent round trips per thread: +16 us on the 12 us argmax)
+        uint32_t gt8[CONF && !GT64 ? ARG_ROWS : 1];
+        long long gt64[CONF && GT64 ? ARG_ROWS : 1][4];
         if (CONF) {
-            const size_t pix = ((size_t)m * H + (size_t)band * ARG_ROWS + ry) * W + gx * 4;
-            long long g4[4];
-            if (GT64) {
-                const long long* gp = reinterpret_cast<const long long*>(gt) + pix;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g4[e] = gp[e];
-            } else {
-                const uint32_t gw = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(gt) + pix);
+            for (int ry = 0; ry < ARG_ROWS; ++ry) {
+                const size_t pix = ((size_t)m * H + band * ARG_ROWS + ry) * W + gx * 4;
+                if (GT64) {
+                    const long long* gp = reinterpret_cast<const long long*>(gt) + pix;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g4[e] = (gw >> (8 * e)) & 0xFF;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool ok = g4[e] >= 0 && g4[e] < ncls;
-                const int bin = ok ? (int)g4[e] * ncls + bi[e] : -1;
-                // one LDS atomic per bin for the wave's two most frequent-first bins (segments are large: usually that is all),
-                // per-lane atomics for the rest.  (Peeling EVERY distinct bin off with ballots is slower on noise-like labels --
-                // the synthetic benchmark's -- than the conflicting atomics it avoids: 1.328 vs 1.275 ms per evaluator step.)
-                unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);              // lanes that still have to be counted
-                const int lane = (int)(threadIdx.x & 63);
-#pragma unroll
-                for (int it = 0; it < 2 && todo; ++it) {                                // wave-uniform: the two most likely bins
-                    const int leader = __builtin_ctzll(todo);
-                    const int b0 = __builtin_amdgcn_readlane(bin, leader);
-                    const unsigned long long same = __builtin_amdgcn_ballot_w64(ok && bin == b0) & todo;
-                    if (lane == leader) atomicAdd(&lh[b0], (unsigned)__builtin_popcountll(same));
-                    todo &= ~same;
+                    for (int e = 0; e < 4; ++e) gt64[GT64 ? ry : 0][e] = gp[e];
+                } else {
+                    gt8[GT64 ? 0 : ry] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(gt) + pix);
                 }
-                if ((todo >> lane) & 1ull) atomicAdd(&lh[bin], 1u);                     // whatever is left (noise-like labels): per lane
             }
         }
+        for (int cbase = 0; cbase < (MULTI ? ncls : 1); cbase += ARG_MAXC) {
+        // the four corners' class vectors (lcs >= 4 ceil(ncls / 4) floats, 16-byte aligned rows: checked by the launcher)
+        f32x4_t c00[3], c01[3], c10[3], c11[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            if (cbase + 4 * v < ncls) {
+                c00[v] = *reinterpret_cast<const f32x4_t*>(lm + (size_t)(y0 * w + x0) * lcs + cbase + 4 * v);
+                c01[v] = *reinterpret_cast<const f32x4_t*>(lm + (size_t)(y0 * w + x1) * lcs + cbase + 4 * v);
+                c10[v] = *reinterpret_cast<const f32x4_t*>(lm + (size_t)(y1 * w + x0) * lcs + cbase + 4 * v);
+                c11[v] = *reinterpret_cast<const f32x4_t*>(lm + (size_t)(y1 * w + x1) * lcs + cbase + 4 * v);
+            } else {
+                c00[v] = c01[v] = c10[v] = c11[v] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // horizontal lerps, once per (class, column): lerp2d's `top` and `bot`
+        float top[ARG_MAXC][4], bot[ARG_MAXC][4];
+#pragma unroll
+        for (int c = 0; c < ARG_MAXC; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                top[c][e] = __builtin_fmaf(lx1[e], c01[c >> 2][c & 3], lx0[e] * c00[c >> 2][c & 3]);
+                bot[c][e] = __builtin_fmaf(lx1[e], c11[c >> 2][c & 3], lx0[e] * c10[c >> 2][c & 3]);
+            }
+        }
+        const bool last_chunk = !MULTI || cbase + ARG_MAXC >= ncls;
+#pragma unroll
+        for (int ry = 0; ry < ARG_ROWS; ++ry) {
+            const int oy = band * ARG_ROWS + ry;
+            float syr = (oy + 0.5f) * 0.03125f - 0.5f;
+            syr = syr < 0.f ? 0.f : syr;
+            const float ly1 = syr - (float)y0, ly0 = 1.f - ly1;
+            float best[4];
+            int bi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                best[e] = MULTI ? bestr[MULTI ? ry : 0][e] : -INFINITY;
+                bi[e] = MULTI ? bir[MULTI ? ry : 0][e] : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < ARG_MAXC; ++c) {
+                if (cbase + c < ncls) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __builtin_fmaf(ly1, bot[c][e], ly0 * top[c][e]);
+                        if (v > best[e]) { best[e] = v; bi[e] = cbase + c; }
+                    }
+                }
+            }
+            if (MULTI) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bestr[MULTI ? ry : 0][e] = best[e]; bir[MULTI ? ry : 0][e] = bi[e]; }
+            }
+            if (!last_chunk) continue;
+            const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+            if (labels) *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W) = packed;
+            if (CONF) {
+                int bin[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long g = GT64 ? gt64[GT64 ? ry : 0][e] : (long long)((gt8[GT64 ? 0 : ry] >> (8 * e)) & 0xFF);
+                    bin[e] = (g >= 0 && g < ncls) ? (int)g * ncls + bi[e] : -1;
+                }
+                const int lane = (int)(threadIdx.x & 63);
+                // the common case inside a segment: every pixel of the wave's row (64 lanes x 4 columns) falls in ONE bin -> one atomic
+                const int lead = __builtin_amdgcn_readfirstlane(bin[0]);
+                const int diff = (bin[0] ^ lead) | (bin[1] ^ lead) | (bin[2] ^ lead) | (bin[3] ^ lead);
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+                if (lead >= 0 && __builtin_amdgcn_ballot_w64(diff == 0) == active) {
+                    if (lane == __builtin_ctzll(active)) atomicAdd(&lh[lead], 4u * (unsigned)__builtin_popcountll(active));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // one LDS atomic per bin for the wave's two most frequent-first bins (segment borders: usually that is all),
+                        // per-lane atomics for the rest.  (Peeling EVERY distinct bin off with ballots is slower on noise-like labels --
+                        // the synthetic benchmark's -- than the conflicting atomics it avoids: 1.328 vs 1.275 ms per evaluator step.)
+                        const bool ok = bin[e] >= 0;
+                        unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);          // lanes that still have to be counted
+#pragma unroll
+                        for (int it = 0; it < 2 && todo; ++it) {                            // wave-uniform: the two most likely bins
+                            const int leader = __builtin_ctzll(todo);
+                            const int b0 = __builtin_amdgcn_readlane(bin[e], leader);
+                            const unsigned long long same = __builtin_amdgcn_ballot_w64(ok && bin[e] == b0) & todo;
+                            if (lane == leader) atomicAdd(&lh[b0], (unsigned)__builtin_popcountll(same));
+                            todo &= ~same;
+                        }
+                        if ((todo >> lane) & 1ull) atomicAdd(&lh[bin[e]], 1u);              // whatever is left (noise-like labels): per lane
+                    }
+                }
+            }
+        }
+        }   // class chunks
     }
     if (CONF) {
         __syncthreads();
@@ -279,15 +356,37 @@ extern "C" int w2c_upsample_bilinear32_backward(const float* gout, int M, int h,
     return w2c_launch_status();
 }
 
+// grid of the argmax kernels: (band, column-quad) items of an image in workgroups of 256, M images
+// conf: every workgroup ends with one global atomic per non-zero bin of its histogram -- n^2 hot addresses -- so the confusion form
+// runs ~1024 grid-striding workgroups instead of one per 256 items (cfg 2: 640 x 20: 1.5 M atomics on 121 addresses cost more than
+// the argmax itself)
+static dim3 argmax_grid(int M, int h, int w, bool conf = false) {
+    const int items = (h * 32 / ARG_ROWS) * (w * 32 / 4);
+    int gx = (items + 255) / 256;
+    if (conf) {
+        const int cap = (1024 + M - 1) / M;
+        if (gx > cap) gx = cap;
+    }
+    return dim3((unsigned)gx, (unsigned)M);
+}
+static bool argmax_args_ok(const float* low, int low_cstride, int n_classes) {
+    // the kernel reads the classes of a low-resolution pixel as 16-byte vectors
+    return (low_cstride % 4) == 0 && low_cstride >= (n_classes + 3) / 4 * 4 && !(reinterpret_cast<uintptr_t>(low) & 15);
+}
+
 extern "C" int w2c_upsample32_argmax(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                                      uint8_t* labels, w2c_stream_t stream) {
     w2c_clear_error();
     if (!low || !labels || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || n_classes > 255 || low_cstride < n_classes)
         return W2C_E_ARG;
-    const size_t lds = (size_t)n_classes * h * w * 4;
-    if (lds > 64 * 1024) return W2C_E_ARG;
-    hipLaunchKernelGGL((upsample32_argmax_kernel<false, false>), dim3(h * (32 / ARG_ROWS), M), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                       low, h, w, low_cstride, n_classes, labels, nullptr, nullptr);
+    if (!argmax_args_ok(low, low_cstride, n_classes)) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n_classes <= ARG_MAXC)
+        hipLaunchKernelGGL((upsample32_argmax_kernel<false, false, false>), argmax_grid(M, h, w), dim3(256), 0, s, low, h, w, low_cstride,
+                           n_classes, labels, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((upsample32_argmax_kernel<false, false, true>), argmax_grid(M, h, w), dim3(256), 0, s, low, h, w, low_cstride,
+                           n_classes, labels, nullptr, nullptr);
     return w2c_launch_status();
 }
 
@@ -297,20 +396,23 @@ extern "C" int w2c_upsample32_argmax_confusion(const float* low, int M, int h, i
     w2c_clear_error();
     if (!low || !gt || !hist || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || n_classes > 64 || low_cstride < n_classes)
         return W2C_E_ARG;
+    if (!argmax_args_ok(low, low_cstride, n_classes)) return W2C_E_ARG;
     // (a tagged pointer -- bit 0 set: the address of a pointer slot -- is resolved on the device; its target's alignment is the caller's to keep)
     if ((!(reinterpret_cast<uintptr_t>(gt) & 1) && (reinterpret_cast<uintptr_t>(gt) & (gt_is_i64 ? 7 : 3))) ||
         (!(reinterpret_cast<uintptr_t>(hist) & 1) && (reinterpret_cast<uintptr_t>(hist) & 7)))
         return W2C_E_ARG;
-    const size_t lds = (size_t)n_classes * h * w * 4 + (size_t)n_classes * n_classes * 4;
-    if (lds > 64 * 1024) return W2C_E_ARG;
+    const size_t lds = (size_t)n_classes * n_classes * 4;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned long long* hp = reinterpret_cast<unsigned long long*>(hist);
-    if (gt_is_i64)
-        hipLaunchKernelGGL((upsample32_argmax_kernel<true, true>), dim3(h * (32 / ARG_ROWS), M), dim3(256), lds, s, low, h, w, low_cstride,
-                           n_classes, labels, gt, hp);
-    else
-        hipLaunchKernelGGL((upsample32_argmax_kernel<true, false>), dim3(h * (32 / ARG_ROWS), M), dim3(256), lds, s, low, h, w, low_cstride,
-                           n_classes, labels, gt, hp);
+    const dim3 grid = argmax_grid(M, h, w, true);
+    const bool multi = n_classes > ARG_MAXC;
+    if (gt_is_i64) {
+        if (multi) hipLaunchKernelGGL((upsample32_argmax_kernel<true, true, true>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
+        else hipLaunchKernelGGL((upsample32_argmax_kernel<true, true, false>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
+    } else {
+        if (multi) hipLaunchKernelGGL((upsample32_argmax_kernel<true, false, true>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
+        else hipLaunchKernelGGL((upsample32_argmax_kernel<true, false, false>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
+    }
     return w2c_launch_status();
 }
 

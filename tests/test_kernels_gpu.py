@@ -702,18 +702,26 @@ def test_upsample_matches_interpolate(M, h, w):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-6, rtol=1e-6)
 
 
-@pytest.mark.parametrize("M,h,w", [(3, 4, 4), (20, 16, 16), (1, 8, 5)])
-def test_upsample_argmax_equals_argmax_of_upsample(M, h, w):
-    """SURVEY 8f row 4 (trainer.py:804): fused labels == outputs.max(1)[1] of the unfused K9 output, bit for bit."""
+@pytest.mark.parametrize("M,h,w,ncls,lcs", [(3, 4, 4, 11, 32), (20, 16, 16, 11, 32), (1, 8, 5, 11, 32), (2, 4, 6, 21, 32), (2, 3, 4, 12, 12),
+                                            (1, 2, 2, 3, 4), (1, 4, 4, 25, 28)])
+def test_upsample_argmax_equals_argmax_of_upsample(M, h, w, ncls, lcs):
+    """SURVEY 8f row 4 (trainer.py:804): fused labels == outputs.max(1)[1] of the unfused K9 output, bit for bit -- for the register
+    form (<= 12 classes: one pass) and the chunked form (more classes: 12 at a time, running best kept per row); ties keep the
+    lowest index (a duplicated class plane)."""
     from multiagentperception_amd import ops
-    gen = torch.Generator().manual_seed(M + h + w)
-    lowd = torch.randn(M, h, w, 32, generator=gen).to(_dev())
-    lowd[..., 11:] = 100.0                                          # padding channels must never win
-    full = ops.upsample_bilinear32(lowd, 11)
-    lab = ops.upsample32_argmax(lowd, 11)
+    gen = torch.Generator().manual_seed(M + h + w + ncls)
+    lowd = torch.randn(M, h, w, lcs, generator=gen)
+    lowd[..., ncls:] = 100.0                                        # padding channels must never win
+    if ncls > 4:
+        lowd[..., ncls - 1] = lowd[..., 1]                          # exact ties between class 1 and the last class
+    lowd = lowd.to(_dev())
+    full = ops.upsample_bilinear32(lowd, ncls)
+    lab = ops.upsample32_argmax(lowd, ncls)
     torch.cuda.synchronize()
     assert lab.dtype == torch.uint8 and lab.shape == (M, 32 * h, 32 * w)
     assert torch.equal(lab.long(), full.max(1)[1])
+    if ncls > 4:
+        assert int((lab == ncls - 1).sum()) == 0                    # the tie always goes to the lower index
 
 
 @pytest.mark.parametrize("cout,B,N,H,W", [(128, 2, 3, 64, 128), (64, 1, 2, 128, 128), (128, 1, 1, 16, 64)])
