@@ -458,7 +458,8 @@ def main():
                               frames_per_s=round(B * args.steps / elapsed, 2),
                               parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
                               launch=("hip-graph replay" if (world == 1 and not args.force_sharded) else
-                                      "3 hip-graph segments + eager collectives")
+                                      ("sharded: " + fwd.launch_form if "one hip-graph" in getattr(fwd, "launch_form", "")
+                                       else "3 hip-graph segments + eager collectives"))
                               if model.use_hip_graph else "eager"),
                   roofline=roofline)
 

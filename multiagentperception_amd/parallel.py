@@ -21,6 +21,8 @@ import os
 import torch
 import torch.distributed as dist
 
+_ONE_GRAPH = os.environ.get("W2C_SHARD_ONE_GRAPH", "1") != "0"     # the sharded softmax step as one captured graph (nccl backend only)
+
 
 def _as_bytes_view(t):
     """all-gather the raw bytes (flat uint8 view): every backend (RCCL, gloo) moves uint8, not every
@@ -195,6 +197,8 @@ class AgentParallelForward:
         # only way to execute the RCCL calls and their interplay with graph capture on a single-GPU box (tests, bench
         # --force-sharded); results equal forward_local's bit for bit
         self.force_sharded = os.environ.get("W2C_FORCE_SHARDED", "0") == "1"
+        self._one_graph_ok = True
+        self.launch_form = "eager"
 
     def _state(self, eng, x):
         cache = eng.__dict__.setdefault("_shard_states", {})          # dies with the engine (load_state_dict / .to() / train())
@@ -219,6 +223,15 @@ class AgentParallelForward:
             x = inputs_local.contiguous().float()
             if self.world == 1 and not (self.force_sharded and dist.is_initialized()):
                 return eng.forward_local(x, B, N, inference, use_graph=use_graph)
+            if (inference == "softmax" and use_graph and _ONE_GRAPH and not eng.trunk.n8 and self._one_graph_ok
+                    and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+                try:
+                    return self._softmax_one_graph(eng, x, B, N)
+                except RuntimeError as e:       # capture refused (an RCCL build that cannot be captured): the segment form below
+                    import warnings
+                    warnings.warn("agent-parallel forward: one-graph capture failed (%s); using 3 graph segments + eager collectives" % (e,))
+                    self._one_graph_ok = False
+                    eng.__dict__.pop("_shard_states", None)
             st = self.encode_local(eng, x, use_graph)
             if inference != "softmax":
                 return self._sparse(eng, st, inference, use_graph)
@@ -234,6 +247,74 @@ class AgentParallelForward:
         if use_graph:
             prob, action, nnz = prob.clone(), action.clone(), nnz.clone()
         return pred, prob, action, nnz
+
+    def _softmax_one_graph(self, eng, x, B, N):
+        """The whole sharded 'softmax' step of a rank as ONE captured HIP graph (round 4), RCCL all-gathers included:
+            stem (reads the caller's frames through a pointer slot) -> layer1 (both trunks) -> fork
+              value chain : layer2..4, squeezer, decoder conv0 on the local value maps (U, into this rank's rows of the gather buffer),
+                            in-place all-gather of U  -- issued from the value chain, so it travels under the policy chain's tail
+              policy chain: layer2..4, squeezer, policy conv1..5, heads (projected keys into this rank's rows), all-gather of K
+            join -> graph columns of the local queries + fusion of the U maps + bias + ReLU -> decoder's last conv -> x32 upsample into
+            the caller-owned logits (pointer slot) -> packed prob / action / nnz into the caller-owned copy.
+        Per step the host issues one slot-setting launch and one replay (the 3-segment form: stem + 3 replays + 2 collectives +
+        upsample + 3 clones).  Needs the nccl (RCCL) backend: its collectives are stream operations and can be captured."""
+        from . import ops
+        st = self._state(eng, x)
+        n_loc, q_lo = self.n_loc, self.q_lo
+        dev = x.device
+        H, W = x.shape[2], x.shape[3]
+        out = torch.empty((n_loc * B, eng.n_classes, H, W), dtype=torch.float32, device=dev)
+        ent = st.graphs.get("whole")
+        if ent is None:
+            slots = torch.zeros(8, dtype=torch.int64, device=dev)
+            xs = ops.SlotRef(slots, 0, x)
+            outs = ops.SlotRef(slots, 1, out)
+            rows = n_loc * B
+
+            def whole():
+                eng.trunk.stem(xs, n_loc, out=st.s0)
+                works = []
+
+                def value_tail(v):
+                    u = eng.value_maps(v, out=st.v_slot)
+                    works.append(_gather_inplace(st.v_all, self.rank, rows, self.group))
+                    return u
+
+                def policy_tail(pol):
+                    y = eng.policy_convs(pol, ch_off=0, gate=True)
+                    eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
+                    works.append(_gather_inplace(st.k_all, self.rank, rows, self.group))
+                    return y
+
+                eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
+                for wk in works:
+                    exchange_wait(wk)
+                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, "softmax")
+                pack = eng._last_pack
+                ops.upsample_bilinear32(low, eng.n_classes, out=outs)
+                ops.copy_to_slot(pack, ops.SlotRef(slots, 2, pack))
+                return pack
+
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                pack0 = ops.graph_outputs(dev, B, N, n_loc)[0]
+                ops.set_slots(slots, [x, out, pack0])
+                for _ in range(2):                       # warm-up: func attributes, head plans, allocator, RCCL's lazy init
+                    whole()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                pack = whole()
+            ent = st.graphs["whole"] = (graph, slots, pack)
+        graph, slots, pack = ent
+        packc = torch.empty_like(pack)
+        ops.set_slots(slots, [x, out, packc])
+        graph.replay()
+        self.launch_form = "one hip-graph incl. the RCCL all-gathers"
+        prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
+        return out, prob, action, nnz
 
     def encode_local(self, eng, x, use_graph=False):
         """stem + segment A on this rank's frames: the U maps of the local agents (decoder conv0 of their value maps) land in
