@@ -345,7 +345,7 @@ int w2c_comm_graph_fuse(const float* query, const float* tproj, int B, int N, in
  * x     : bf16 [M <= 64][x_stride] policy map rows (K = 4096 features each)
  * wfrag : f32 fc.0 weights of all heads stacked along O ([O][K]), FRAGMENT-PACKED:
  *         wfrag[((o / 32) * (K / 8) + q) * 256 + (half * 32 + o % 32) * 4 + e] = W[o][8 q + 4 half + e]
- * part  : f32 [ksplit][M][O] split-K partial sums (no bias, no ReLU); K % (128 ksplit) == 0, O % 32 == 0
+ * part  : f32 [ksplit][M][O] split-K partial sums (no bias, no ReLU); K % (256 ksplit) == 0, O % 32 == 0
  * w2c_head_tail2p_f32 = w2c_head_tail2_f32 reading its fc.0 output as h0 = relu(sum_p part[p] + b0) (added in p order). */
 int w2c_head_fc0_mfma_f32(const uint16_t* x, int x_stride, int M, int K, const float* wfrag, int O, int ksplit,
                           float* part, w2c_stream_t stream);

@@ -272,6 +272,93 @@ __global__ __launch_bounds__(256) void head_tail2_kernel(const float* __restrict
                    b0 ? b0 + s.col_off : nullptr);
 }
 
+// The two heads' tails on split-K partials of fc.0, WIDE form (round 4): 1024 threads per (row, head) instead of 256, so that each of
+// the three dependent stages -- sum of the partials, fc.2 (K = 256), fc.4 (K = 128) -- is ONE round of loads per thread (the 256-thread
+// body above walks 4 + 4 + 4 rounds of 32 loads: ~10 us of pure latency at the end of the policy chain).  Same three stages, fixed
+// summation orders (deterministic); taken when 1024 % K1 == 0, 1024 % H1 == 0, n_part % (1024 / K1) == 0 and both heads have <= 64 outputs.
+__global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restrict__ part, int n_part, long part_stride,
+                                                           const float* __restrict__ b0, int h0_stride, int K1, int H1,
+                                                           HeadTailSet a, HeadTailSet b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_h0 = reinterpret_cast<float*>(smem);          // [K1]
+    float* s_h1 = s_h0 + K1;                               // [H1]
+    float* s_part = s_h1 + H1;                             // [1024]
+    const HeadTailSet& s = blockIdx.y == 0 ? a : b;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    {   // stage 0: h0[k] = relu(sum_p part_p[m][col_off + k] + b0): thread = (k, group of n_part / G consecutive partials)
+        const int G = 1024 / K1, per = n_part / G;
+        const int k = tid % K1, g = tid / K1;
+        const float* src = part + (size_t)m * h0_stride + s.col_off + k + (size_t)g * per * part_stride;
+        float v = 0.f;
+        int pp = 0;
+        for (; pp + 4 <= per; pp += 4) {
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = src[(size_t)(pp + u) * part_stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += t[u];
+        }
+        for (; pp < per; ++pp) v += src[(size_t)pp * part_stride];
+        s_part[tid] = v;
+        __syncthreads();
+        if (tid < K1) {
+            float t = s_part[tid];
+            for (int gg = 1; gg < G; ++gg) t += s_part[gg * K1 + tid];
+            s_h0[tid] = fmaxf(t + b0[s.col_off + tid], 0.f);
+        }
+        __syncthreads();
+    }
+    {   // stage 1: h1 = relu(W1 h0 + b1): thread = (output j, K partition): k = p + i P
+        const int P = 1024 / H1, j = tid % H1, p = tid / H1;
+        const int kn = (K1 - p + P - 1) / P;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 32 <= kn; i += 32) {
+            float wv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) wv[u] = s.w1t[(size_t)(p + (i + u) * P) * H1 + j];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc[u & 3] = fmaf(wv[u], s_h0[p + (i + u) * P], acc[u & 3]);
+        }
+        for (; i < kn; ++i) acc[0] = fmaf(s.w1t[(size_t)(p + i * P) * H1 + j], s_h0[p + i * P], acc[0]);
+        s_part[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (tid < H1) {
+            float v = s.b1[tid];
+            for (int pp = 0; pp < P; ++pp) v += s_part[pp * H1 + tid];
+            s_h1[tid] = fmaxf(v, 0.f);
+        }
+        __syncthreads();
+    }
+    {   // stage 2: out = W2 h1 + b2 (O <= 64): thread = (output o, K partition of 16)
+        const int o = tid & 63, p = tid >> 6;              // 16 partitions
+        float acc = 0.f;
+        if (o < s.O) {
+            float wv[16];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = p + u * 16;
+                wv[u] = k < H1 ? s.w2t[(size_t)k * s.O + o] : 0.f;
+                n = u;
+            }
+            (void)n;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = p + u * 16;
+                if (k < H1) acc = fmaf(wv[u], s_h1[k], acc);
+            }
+        }
+        s_part[tid] = acc;
+        __syncthreads();
+        if (tid < s.O) {
+            float v = s.b2[tid];
+            for (int pp = 0; pp < 16; ++pp) v += s_part[pp * 64 + tid];
+            s.out[(size_t)m * s.O + tid] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K5, round 4: fc.0 of the heads on the f32 matrix pipe
 // y[m][o] = sum_k x[m][k] W[o][k]  (M = 20 .. 128 rows, K = 4096, O = 512: 84 MFLOP, 8 MB of f32 weights).  The VALU form above
 // (linear_widek_kernel: one workgroup per output column, every workgroup re-reads all M rows of x) took 25-28 us at the END of the
@@ -307,17 +394,18 @@ __global__ __launch_bounds__(256) void head_fc0_mfma_kernel(const uint16_t* __re
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
-    for (int q = 0; q < nq; q += 4) {                        // 4 blocks (32 k) of loads in flight
-        f32x4_t wv[4];
-        uint2 xv[4][RB];
+    constexpr int QD = RB == 1 ? 8 : 4;                      // blocks (8 k each) of loads in flight: a 64-deep K slice is ONE round for M <= 32
+    for (int q = 0; q < nq; q += QD) {
+        f32x4_t wv[QD];
+        uint2 xv[QD][RB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < QD; ++u) {
             wv[u] = wp[(size_t)(q + u) * 64];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) xv[u][rb] = *reinterpret_cast<const uint2*>(xp[rb] + (q + u) * 8);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < QD; ++u)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const float xe[4] = {__uint_as_float(xv[u][rb].x << 16), __uint_as_float(xv[u][rb].x & 0xFFFF0000u),
@@ -791,7 +879,7 @@ extern "C" int w2c_head_fc0_mfma_f32(const uint16_t* x, int x_stride, int M, int
                                      float* part, w2c_stream_t stream) {
     w2c_clear_error();
     if (!x || !wfrag || !part || M <= 0 || M > 64 || K <= 0 || O <= 0 || (O % 32) != 0 || ksplit <= 0) return W2C_E_ARG;
-    if ((K % (ksplit * 128)) != 0 || (x_stride % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(wfrag) & 15))
+    if ((K % (ksplit * 256)) != 0 || (x_stride % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(wfrag) & 15))
         return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M <= 32) hipLaunchKernelGGL((head_fc0_mfma_kernel<1>), dim3(O / 32, ksplit), dim3(256), 0, s, x, x_stride, M, K, wfrag, O, part);
@@ -812,6 +900,11 @@ extern "C" int w2c_head_tail2p_f32(const float* part, int n_part, long long part
     const size_t lds = (size_t)(K1 + H1 + 256) * 4;
     const int omax = O_a > O_b ? O_a : O_b;
     HeadTailSet a{w1t_a, b1_a, w2t_a, b2_a, out_a, col_off_a, O_a}, b{w1t_b, b1_b, w2t_b, b2_b, out_b, col_off_b, O_b};
+    if (omax <= 64 && K1 <= 1024 && (1024 % K1) == 0 && (1024 % H1) == 0 && H1 <= 256 && (n_part % (1024 / K1)) == 0) {
+        hipLaunchKernelGGL(head_tail2w_kernel, dim3(M, 2), dim3(1024), (size_t)(K1 + H1 + 1024) * 4, reinterpret_cast<hipStream_t>(stream),
+                           part, n_part, (long)part_stride, b0, h0_stride, K1, H1, a, b);
+        return w2c_launch_status();
+    }
     hipLaunchKernelGGL(head_tail2_kernel, dim3(M, (omax + 255) / 256, 2), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        part, h0_stride, K1, H1, a, b, n_part, (long)part_stride, b0);
     return w2c_launch_status();

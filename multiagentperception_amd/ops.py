@@ -844,7 +844,7 @@ HEAD_FC0_KSPLIT = 16
 
 
 def head_fc0_supported(M, K, O, ksplit=HEAD_FC0_KSPLIT):
-    return M <= 64 and O % 32 == 0 and K % (ksplit * 128) == 0
+    return M <= 64 and O % 32 == 0 and K % (ksplit * 256) == 0
 
 
 def head_fc0_mfma(x, x_stride, M, K, wfrag, O, ksplit=HEAD_FC0_KSPLIT, part=None):

@@ -232,6 +232,7 @@ class AgentParallelForward:
                     warnings.warn("agent-parallel forward: one-graph capture failed (%s); using 3 graph segments + eager collectives" % (e,))
                     self._one_graph_ok = False
                     eng.__dict__.pop("_shard_states", None)
+            self.launch_form = "3 hip-graph segments + eager collectives" if use_graph else "eager"
             st = self.encode_local(eng, x, use_graph)
             if inference != "softmax":
                 return self._sparse(eng, st, inference, use_graph)
