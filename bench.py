@@ -369,6 +369,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
+    launch_form = getattr(fwd, "launch_form", "")            # what the TIMED steps ran as (later legs may take other paths)
     images_per_step = B * N
     value = images_per_step * args.steps / elapsed
 
@@ -458,7 +459,7 @@ def main():
                               frames_per_s=round(B * args.steps / elapsed, 2),
                               parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
                               launch=("hip-graph replay" if (world == 1 and not args.force_sharded) else
-                                      ("sharded: " + fwd.launch_form if "one hip-graph" in getattr(fwd, "launch_form", "")
+                                      ("sharded: " + launch_form if "one hip-graph" in launch_form
                                        else "3 hip-graph segments + eager collectives"))
                               if model.use_hip_graph else "eager"),
                   roofline=roofline)

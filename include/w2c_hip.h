@@ -360,12 +360,14 @@ int w2c_head_tail2p_f32(const float* part, int n_part, long long part_stride, co
  *          MIMOcomWho (decoder input cat(fused, V[q]), agent.py:1382): channels [own_off, own_off + C) = the conv of V with the
  *          second half of conv0's filters; own_off < 0: none
  *   out  : bf16 NHWC rows [q_n*B][hw][out_cstride]: row (q*B+b) = relu(sum_k coef[b,k,q] * u[k*B+b] (+ u_own[(q_lo+q)*B+b]) + bias)
- *          = relu(conv0(fused map)), summed in f32 and rounded once; graph outputs as in w2c_comm_graph_fuse. */
+ *          = relu(conv0(fused map)), summed in f32 and rounded once; graph outputs as in w2c_comm_graph_fuse.
+ *   pack2: optional [indirect-capable] second copy of the graph outputs, packed: prob f32 [B,N,q_n] at byte 0, action i64 [B,q_n] at
+ *          act_off, nnz i32 [B] at nnz_off (act_off % 8 == 0, nnz_off % 4 == 0) -- a captured forward's caller-owned outputs. */
 int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
                           float thres, float tie_bias, int q_lo, int q_n,
                           float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
                           const float* u, int u_cstride, int hw, int C, int own_off, const float* bias,
-                          uint16_t* out, int out_cstride, w2c_stream_t stream);
+                          uint16_t* out, int out_cstride, void* pack2, long long act_off, long long nnz_off, w2c_stream_t stream);
 
 /* ---- Indirect operands (round 4).  The module boundary hands the forward a caller-owned input tensor and returns caller-owned
  * output tensors (SURVEY 8b "Ownership"), so the first and the last kernel of a forward touch addresses that change from call to

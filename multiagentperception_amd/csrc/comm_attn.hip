@@ -734,7 +734,12 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
                                                            int q_lo, int q_n, float* __restrict__ prob, float* __restrict__ coef,
                                                            int64_t* __restrict__ action, int32_t* __restrict__ nnz,
                                                            const float* __restrict__ u, int ucs, int hw, int C, int own_off,
-                                                           const float* __restrict__ bias, uint16_t* __restrict__ out, int ocs) {
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ out, int ocs,
+                                                           char* pack2_arg, long act_off, long nnz_off) {
+    // pack2 (optional, indirect-capable): a second, caller-owned copy of the packed prob | action | nnz (same layout as the buffer
+    // prob / action / nnz point into: action at act_off bytes, nnz at nnz_off) -- the captured forward's outputs land in the caller's
+    // tensor without a copy launch of their own
+    char* const pack2 = w2c_resolve(pack2_arg);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cs = reinterpret_cast<float*>(smem);          // [N][q_n] for this b, then one int
     int* cnt = reinterpret_cast<int*>(cs + N * q_n);
@@ -754,16 +759,23 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
                 const size_t o = ((size_t)b * N + lane) * q_n + ql;
                 prob[o] = pr;
                 coef[o] = cf;
+                if (pack2) reinterpret_cast<float*>(pack2)[o] = pr;
             }
         }
-        if (writer && lane == 0) action[(size_t)b * q_n + ql] = act;
+        if (writer && lane == 0) {
+            action[(size_t)b * q_n + ql] = act;
+            if (pack2) reinterpret_cast<int64_t*>(pack2 + act_off)[(size_t)b * q_n + ql] = act;
+        }
     }
     if (writer) {
         local_nnz = (int)wave_sum((float)local_nnz);
         if (lane == 0 && local_nnz) atomicAdd(cnt, local_nnz);
     }
     __syncthreads();
-    if (writer && tid == 0) nnz[b] = *cnt;
+    if (writer && tid == 0) {
+        nnz[b] = *cnt;
+        if (pack2) reinterpret_cast<int32_t*>(pack2 + nnz_off)[b] = *cnt;
+    }
     const int CG = C >> 2;
     const int total = hw * CG;
     for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
@@ -980,7 +992,7 @@ extern "C" int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int
                                      float thres, float tie_bias, int q_lo, int q_n,
                                      float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
                                      const float* u, int u_cstride, int hw, int C, int own_off, const float* bias,
-                                     uint16_t* out, int out_cstride, w2c_stream_t stream) {
+                                     uint16_t* out, int out_cstride, void* pack2, long long act_off, long long nnz_off, w2c_stream_t stream) {
     w2c_clear_error();
     if (!tproj || !prob || !coef || !action || !nnz_offdiag || !u || !bias || !out) return W2C_E_ARG;
     if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
@@ -994,6 +1006,6 @@ extern "C" int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int
     const size_t lds = (size_t)N * q_n * 4 + 16;
     hipLaunchKernelGGL(graph_fuse_u_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), query, tproj, B, N, Dq,
                        who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag, u, u_cstride, hw, C, own_off < 0 ? -1 : own_off,
-                       bias, out, out_cstride);
+                       bias, out, out_cstride, reinterpret_cast<char*>(pack2), (long)act_off, (long)nnz_off);
     return w2c_launch_status();
 }

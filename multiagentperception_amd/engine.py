@@ -662,13 +662,13 @@ class CommEngine:
         sq, (keys, querys), u = self.trunk.after_stem(s0, policy_next=(self.policy_convs, self.policy_heads), value_next=self.value_maps)
         return sq, u, keys, querys
 
-    def graph_and_low(self, u_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
+    def graph_and_low(self, u_all, keys_all, querys_local, B, N, q_lo, q_n, mode, pack2=None):
         """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion of the agents' U maps (+ bias + ReLU
         = the decoder's first layer), the decoder's last conv: everything up to the low-resolution logits.
         u_all: f32 NHWC [N*B,h,w,C | 2C] from value_maps (rows of agents whose coefficient is 0 for every local query are not read)."""
         d = self.decoder
         y, prob, _, action, nnz, pack = ops.comm_graph_fuse_u(querys_local, keys_all, u_all, d.c_hidden, d.cu_bias, B, N, self.who, mode,
-                                                              q_lo=q_lo, q_n=q_n, own_off=d.own_off)
+                                                              q_lo=q_lo, q_n=q_n, own_off=d.own_off, pack2=pack2)
         self._last_pack = pack             # prob / action / nnz are views of this one buffer (ops.graph_outputs)
         _stamp(24)
         low = d.c2.run(y, out_f32=True)
@@ -755,7 +755,8 @@ class CommEngine:
         def whole():
             s0 = self.trunk.stem(xs, N)
             _, u, keys, querys = self.encode_from_stem(s0)
-            low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode)
+            pack2 = ops.SlotRef(slots, self._SLOT_PACK, ops.graph_outputs(dev, B, N, N)[0])
+            low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode, pack2=pack2)
             pack = self._last_pack
             if confusion is not None:
                 ops.upsample32_argmax_confusion(low, self.n_classes, gts, hists, want_labels=labels, out=outs)
@@ -763,7 +764,6 @@ class CommEngine:
                 ops.upsample32_argmax(low, self.n_classes, out=outs)
             else:
                 ops.upsample_bilinear32(low, self.n_classes, out=outs)
-            ops.copy_to_slot(pack, ops.SlotRef(slots, self._SLOT_PACK, pack))
             return pack
 
         side = torch.cuda.Stream(device=dev)

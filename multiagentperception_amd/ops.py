@@ -961,9 +961,18 @@ def comm_graph_fuse(query, tproj, v, v_ch, B, N, who, mode, thres=0.2, tie_bias=
     return out, prob, coef, action, nnz, pack
 
 
-def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None, own_off=-1):
+def pack_offsets(B, N, q_n):
+    """byte offsets of action / nnz inside the packed graph outputs (graph_outputs)"""
+    n_prob, n_act = B * N * q_n * 4, B * q_n * 8
+    off_act = (n_prob + 7) // 8 * 8
+    return off_act, off_act + n_act
+
+
+def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None, own_off=-1, pack2=None):
     """w2c_comm_graph_fuse_u: graph + fusion of the U maps (decoder conv0 of every agent's value map, no bias, f32 NHWC
-    [N*B,h,w,ucs]) + bias + ReLU -> y bf16 [q_n*B,h,w,C] = relu(conv0(fused map)), prob, coef, action, nnz, pack."""
+    [N*B,h,w,ucs]) + bias + ReLU -> y bf16 [q_n*B,h,w,C] = relu(conv0(fused map)), prob, coef, action, nnz, pack.
+    pack2: optional tensor / SlotRef receiving a second copy of the packed prob | action | nnz (the caller-owned outputs of a
+    captured forward)."""
     dev = _need_gpu(query, tproj, u, bias)
     Dq = tproj.shape[1] - 1
     if q_n is None:
@@ -977,7 +986,8 @@ def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_
     with torch.cuda.device(dev):
         check(_native.lib().w2c_comm_graph_fuse_u(_p(query), _p(tproj), B, N, Dq, 1 if who else 0, MODE_IDS[mode], float(thres),
                                                   float(tie_bias), q_lo, q_n, _p(prob), _p(coef), _p(action), _p(nnz), _p(u), ucs,
-                                                  h * w, C, int(own_off), _p(bias), _p(out), C, _stream(dev)),
+                                                  h * w, C, int(own_off), _p(bias), _p(out), C, _p(pack2), *pack_offsets(B, N, q_n),
+                                                  _stream(dev)),
               "w2c_comm_graph_fuse_u")
     return out, prob, coef, action, nnz, pack
 

@@ -290,10 +290,10 @@ class AgentParallelForward:
                 eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
                 for wk in works:
                     exchange_wait(wk)
-                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, "softmax")
+                pack2 = ops.SlotRef(slots, 2, ops.graph_outputs(dev, B, N, n_loc)[0])
+                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, "softmax", pack2=pack2)
                 pack = eng._last_pack
                 ops.upsample_bilinear32(low, eng.n_classes, out=outs)
-                ops.copy_to_slot(pack, ops.SlotRef(slots, 2, pack))
                 return pack
 
             side = torch.cuda.Stream(device=dev)
