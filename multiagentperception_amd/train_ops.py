@@ -296,3 +296,53 @@ def maxpool3x3s2(pool, x):
             and (pool.kernel_size, pool.stride, pool.padding) == (3, 2, 1)):
         return _MaxPoolFn.apply(x)
     return pool(x)
+
+
+
+class GraphedTrainStep:
+    """One whole training step -- forward, loss, backward, optimizer step -- captured into ONE HIP graph and replayed (round 4; VERDICT r03
+    item 9: the eager step is ~650 launches and host-bound).  Every kernel of the step is a stream operation (the HIP convs / BatchNorm /
+    pooling / loss kernels through ctypes, the stock ops that remain, the optimizer's foreach kernels), shapes are static and the
+    reductions are deterministic, so a replay reproduces the eager step bit for bit.
+
+        step = GraphedTrainStep(model, optimizer, loss_fn, example_inputs, example_labels, forward_kwargs=dict(training=True, MO_flag=True))
+        loss = step(inputs, labels)          # copies the batch into the captured step's static buffers, replays, returns the loss tensor
+
+    Restrictions (PyTorch's whole-network capture rules): fixed input shapes; no host synchronisation inside the step (the loss's
+    out-of-range-label check is skipped while capturing: run one eager step per epoch, or W2C_CHECK_LABELS=1 eager runs, to keep it);
+    the optimizer must not read the host (SGD / momentum SGD are fine; Adam needs capturable=True); parameters must not be replaced
+    after capture (load_state_dict copies in place: fine)."""
+
+    def __init__(self, model, optimizer, loss_fn, example_inputs, example_labels, forward_kwargs=None, warmup=3):
+        self.model, self.opt = model, optimizer
+        kw = dict(forward_kwargs or {})
+        dev = example_inputs.device
+        self.x = example_inputs.clone()
+        self.labels = example_labels.clone()
+
+        def one():
+            optimizer.zero_grad(set_to_none=True)
+            out = model(self.x, **kw)
+            pred = out[0] if isinstance(out, (tuple, list)) else out
+            loss = loss_fn(pred, self.labels)
+            loss.backward()
+            optimizer.step()
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                 # func attributes, workspaces, autograd buffers, optimizer state
+                one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = one()
+
+    def __call__(self, inputs, labels):
+        self.x.copy_(inputs, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        return self.loss

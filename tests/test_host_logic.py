@@ -299,3 +299,71 @@ def test_pack_wfrag_layout_is_the_mfma_a_fragment_order():
     for (g, nb, cc, tap, kk, half, c) in ((0, 0, 0, 0, 0, 0, 0), (1, 1, 1, 8, 3, 1, 31), (0, 1, 0, 4, 2, 0, 17), (1, 0, 1, 2, 1, 1, 5)):
         k0 = tap * cin + cc * 64 + kk * 16 + half * 8
         assert torch.equal(f[g, nb, cc * 9 + tap, kk, half, c], w[g, nb * 32 + c, k0:k0 + 8])
+
+
+def test_fc0_fragment_packing_follows_the_header_formula():
+    """ops.pack_fc0_frag == the layout include/w2c_hip.h states for w2c_head_fc0_mfma_f32:
+    wfrag[((o / 32) * (K / 8) + q) * 256 + (half * 32 + o % 32) * 4 + e] = W[o][8 q + 4 half + e]."""
+    from multiagentperception_amd import ops
+    O, K = 64, 48
+    w = torch.arange(O * K, dtype=torch.float32).reshape(O, K)
+    f = ops.pack_fc0_frag(w).reshape(-1)
+    for o in (0, 1, 31, 32, 63):
+        for q in (0, 3, 5):
+            for half in (0, 1):
+                for e in (0, 3):
+                    assert float(f[((o // 32) * (K // 8) + q) * 256 + (half * 32 + o % 32) * 4 + e]) == float(w[o, 8 * q + 4 * half + e])
+    assert sorted(f.tolist()) == sorted(w.reshape(-1).tolist())          # a permutation
+    assert ops.head_fc0_supported(20, 4096, 512) and ops.head_fc0_supported(64, 4096, 512)
+    assert not ops.head_fc0_supported(65, 4096, 512) and not ops.head_fc0_supported(20, 4096, 500)
+
+
+def test_pointer_slots_are_tagged_addresses_and_pack_offsets_match_the_packed_layout():
+    """Indirect operands (include/w2c_hip.h): a SlotRef's 'address' is the slot's address with bit 0 set; the byte offsets handed to
+    w2c_comm_graph_fuse_u's pack2 are those of ops.carve_graph_outputs."""
+    from multiagentperception_amd import ops
+
+    class _FakeSlots:                      # a CPU stand-in with the attributes SlotRef reads (no GPU here)
+        dtype, is_cuda, device = torch.int64, True, torch.device("cpu")
+
+        def numel(self):
+            return 8
+
+        def data_ptr(self):
+            return 0x7F0000001000
+
+    like = torch.empty(3, 5, dtype=torch.uint8)
+    r = ops.SlotRef(_FakeSlots(), 2, like)
+    assert r.data_ptr() == (0x7F0000001000 + 16) | 1 and r.shape == (3, 5) and r.dtype == torch.uint8 and r.numel() == 15 and r.dim() == 2
+    with pytest.raises(ops.W2CError):
+        ops.SlotRef(_FakeSlots(), 8, like)
+    for B, N, qn in ((4, 5, 5), (1, 3, 1), (8, 8, 1), (2, 16, 2)):
+        off_act, off_nnz = ops.pack_offsets(B, N, qn)
+        pack = torch.zeros(off_nnz + 4 * B, dtype=torch.uint8)
+        prob, action, nnz = ops.carve_graph_outputs(pack, B, N, qn)
+        assert off_act % 8 == 0 and off_nnz % 4 == 0
+        assert action.data_ptr() - pack.data_ptr() == off_act and nnz.data_ptr() - pack.data_ptr() == off_nnz
+        assert prob.data_ptr() == pack.data_ptr() and prob.shape == (B, N, qn) and action.shape == (B, qn) and nnz.shape == (B,)
+
+
+@pytest.mark.parametrize("who", [False, True])
+def test_decoder_conv0_commutes_with_the_fusion(who):
+    """The identity the round-4 tail rests on (engine.DecoderPlan.value_maps, csrc/comm_attn.hip graph_fuse_u_kernel): simple_decoder's
+    first conv (backbone.py:150-152) is linear before its bias and the fused map is a linear combination of the value maps
+    (agent.py:276-284), so relu(conv0(sum_k P[k,q] V[k]) + b) == relu(sum_k P[k,q] conv0_nobias(V[k]) + b); MIMOcomWho
+    (cat(fused, V[q]), agent.py:1382): + the conv of V[q] with the second half of the filters.  Checked in f64 on the oracle's ops."""
+    g = torch.Generator().manual_seed(3 + int(who))
+    B, N, C, Co, h = 2, 4, 16, 8, 6
+    V = torch.randn(B, N, C, h, h, generator=g, dtype=torch.float64)
+    P = torch.softmax(torch.randn(B, N, N, generator=g, dtype=torch.float64), dim=1)
+    W = torch.randn(Co, 2 * C if who else C, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    fused = orc.fuse(P, V)                                                            # [B, Nq, C, h, w]
+    for q in range(N):
+        x = torch.cat((fused[:, q], V[:, q]), dim=1) if who else fused[:, q]
+        lhs = F.relu(F.conv2d(x, W, b, padding=1))
+        U = torch.stack([F.conv2d(V[:, k], W[:, :C], None, padding=1) for k in range(N)], 1)      # [B, N, Co, h, w]
+        rhs = torch.einsum("bk,bkchw->bchw", P[:, :, q], U) + b.view(1, -1, 1, 1)
+        if who:
+            rhs = rhs + F.conv2d(V[:, q], W[:, C:], None, padding=1)
+        assert float((lhs - F.relu(rhs)).abs().max()) < 1e-10

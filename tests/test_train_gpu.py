@@ -418,3 +418,41 @@ def test_stem_conv_training_forward_and_weight_gradient_match_f64(M, H, W):
     np.testing.assert_allclose(outs[0][0].numpy(), ref.detach().float().numpy(), atol=1e-2, rtol=2 ** -7)      # bf16 output rounding
     scale = float(w64.grad.abs().max())
     np.testing.assert_allclose(outs[0][1].numpy(), w64.grad.float().numpy(), atol=2e-4 * scale + 1e-4, rtol=2e-4)
+
+
+def test_graph_captured_training_step_reproduces_the_eager_step():
+    """train_ops.GraphedTrainStep (round 4): forward + cross_entropy2d + backward + SGD step captured into ONE HIP graph.  With lr = 0 the
+    weights stay put, so the replayed step must return the eager step's loss and gradients -- bit for bit: every kernel of the step is
+    deterministic -- on the capture batch and on another batch copied into its static buffers."""
+    from oracle import filler
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import train_ops
+    from multiagentperception_amd.loss import cross_entropy2d
+    n, b, s = 3, 1, 128
+    train_ops.set_train_backend("hip")
+    model = get_model(_cfg("MIMOcom", n, s, True), 11)
+    filler.apply_to_module(model)
+    model = model.to(_dev()).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    batches = []
+    for seed in (41, 42):
+        batches.append((torch.from_numpy(filler.synthetic_frames(b, n, s, s, seed)).to(_dev()),
+                        torch.from_numpy(filler.synthetic_labels(b * n, s, s, seed)).to(_dev())))
+    eager = []
+    for x, labels in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = cross_entropy2d(model(x, training=True, MO_flag=True)[0], labels)
+        loss.backward()
+        eager.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    del loss
+    opt.zero_grad(set_to_none=True)
+    step = train_ops.GraphedTrainStep(model, opt, cross_entropy2d, batches[0][0], batches[0][1],
+                                      forward_kwargs=dict(training=True, MO_flag=True))
+    for (x, labels), (ref_loss, ref_grads) in zip(batches + batches[:1], eager + eager[:1]):
+        got = step(x, labels)
+        torch.cuda.synchronize()
+        assert torch.equal(got.detach(), ref_loss)
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        assert grads.keys() == ref_grads.keys()
+        for k in grads:
+            assert torch.equal(grads[k], ref_grads[k]), k

@@ -42,3 +42,20 @@ for backend in ("hip", "stock", "hip"):
     dt = (time.perf_counter() - t0) / n
     print("%-5s backend: %.1f ms / training step (%d agents x B=%d x %dx%d; %.0f agent-images/s), loss %.4f, peak mem %.1f GB" % (
         backend, 1e3 * dt, N, B, S, S, N * B / dt, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
+# ---- the same step captured into one HIP graph (train_ops.GraphedTrainStep)
+del loss
+opt.zero_grad(set_to_none=True)
+train_ops.set_train_backend("hip")
+gstep = train_ops.GraphedTrainStep(model, opt, cross_entropy2d, x, labels, forward_kwargs=dict(training=True, MO_flag=True))
+for _ in range(2):
+    gstep(x, labels)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n):
+    loss = gstep(x, labels)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print("hip backend, ONE captured graph per step: %.1f ms / training step (%.0f agent-images/s), loss %.4f" % (1e3 * dt, N * B / dt, float(loss)))
