@@ -31,26 +31,44 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
     __syncthreads();
     const int xq = W >> 2;                              // float4 groups per output row
     float* obase = out + (((size_t)m * ncls + c) * H + (size_t)band * 32) * W;
-    for (int id = threadIdx.x; id < 32 * xq; id += 256) {
-        const int ry = id / xq, gx = id - ry * xq;
-        const int oy = band * 32 + ry;
-        float sy = (oy + 0.5f) * 0.03125f - 0.5f;
+    // Round 4: thread = 4 consecutive columns x a run of 16 output rows.  A 16-row half band (rows [16 k, 16 k + 16)) has ONE pair of
+    // source rows (y0, y1) and a column quad ONE pair of source columns, so lerp2d's horizontal lerps (`top` at y0, `bot` at y1) are
+    // formed once per thread -- 8 LDS reads and 8 lerps for 64 outputs -- and every output is lerp2d's last step alone:
+    // fma(ly1, bot, ly0 * top).  Same operations in the same order as the per-pixel form: same bits.  (The per-pixel form issued 16 LDS
+    // reads and ~40 VALU instructions per 16-byte store: SQ showed it stalled on issue, not on the memory system.)
+    const int halves = 2 * xq;                          // (half band, column quad) items of this workgroup
+    for (int id = threadIdx.x; id < halves; id += 256) {
+        const int hb = id / xq, gx = id - hb * xq;
+        const int oy0 = band * 32 + hb * 16;
+        float sy = (oy0 + 0.5f) * 0.03125f - 0.5f;
         sy = sy < 0.f ? 0.f : sy;
         const int y0 = (int)sy;
         const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-        f32x4_t o;
+        float sx0 = (gx * 4 + 0.5f) * 0.03125f - 0.5f;
+        sx0 = sx0 < 0.f ? 0.f : sx0;
+        const int x0 = (int)sx0;
+        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float p00 = plane[y0 * w + x0], p01 = plane[y0 * w + x1], p10 = plane[y1 * w + x0], p11 = plane[y1 * w + x1];
+        float top[4], bot[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int ox = gx * 4 + e;
-            float sx = (ox + 0.5f) * 0.03125f - 0.5f;
+            float sx = (gx * 4 + e + 0.5f) * 0.03125f - 0.5f;
             sx = sx < 0.f ? 0.f : sx;
-            const int x0 = (int)sx;
-            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
             const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-            o[e] = lerp2d(ly0, ly1, lx0, lx1, plane[y0 * w + x0], plane[y0 * w + x1], plane[y1 * w + x0], plane[y1 * w + x1]);
+            top[e] = __builtin_fmaf(lx1, p01, lx0 * p00);
+            bot[e] = __builtin_fmaf(lx1, p11, lx0 * p10);
         }
-        *reinterpret_cast<f32x4_t*>(obase + (size_t)ry * W + gx * 4) = o;   // (nontemporal stores measured: no gain)
+        float* orow = obase + (size_t)(hb * 16) * W + gx * 4;
+#pragma unroll
+        for (int ry = 0; ry < 16; ++ry) {
+            float syr = (oy0 + ry + 0.5f) * 0.03125f - 0.5f;
+            syr = syr < 0.f ? 0.f : syr;
+            const float ly1 = syr - (float)y0, ly0 = 1.f - ly1;
+            f32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(ly1, bot[e], ly0 * top[e]);
+            *reinterpret_cast<f32x4_t*>(orow + (size_t)ry * W) = o;
+        }
     }
 }
 
