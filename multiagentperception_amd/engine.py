@@ -862,13 +862,60 @@ class SRMSEngine:
         perm = torch.cat([torch.arange(512, 1024), torch.arange(0, 512)]).to(self.wq.device) if self.who else None
         self.decoder = DecoderPlan(model.decoder, self.n_classes, in_perm=perm)
 
-    def forward(self, x, mode):
-        """x f32 [B,15,H,W] -> pred f32 [B,n_cls,H,W], prob [B,K,1] (K = 5, or 4 for who), coef [B,K,1], action [B,1], nnz [B]."""
+    def forward(self, x, mode, use_graph=False):
+        """x f32 [B,15,H,W] -> pred f32 [B,n_cls,H,W], prob [B,K,1] (K = 5, or 4 for who), coef [B,K,1], action [B,1], nnz [B].
+        use_graph (model.use_hip_graph): the whole forward replays from ONE captured HIP graph per (input shape, mode) -- the frames are
+        copied into the graph's static input (the single-request models slice and re-pack channel groups of the input, so the pointer-slot
+        route of the MIMO engines does not apply to them), the x32 upsample writes the caller-owned logits through a pointer slot."""
+        if not use_graph:
+            return self._forward(x, mode)
+        dev = x.device
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        pred = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=dev)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        key = (tuple(x.shape), mode)
+        ent = graphs.get(key)
+        if ent is None:
+            xs = torch.empty_like(x)
+            slots = torch.zeros(8, dtype=torch.int64, device=dev)
+            outs = ops.SlotRef(slots, 0, pred)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                xs.copy_(x)
+                ops.set_slots(slots, [pred])
+                for _ in range(2):
+                    self._forward(xs, mode, out=outs)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                res = self._forward(xs, mode, out=outs)
+            ent = graphs[key] = (graph, xs, slots, res[1:])
+        graph, xs, slots, small = ent
+        xs.copy_(x, non_blocking=True)
+        ops.set_slots(slots, [pred])
+        graph.replay()
+        return (pred,) + tuple(t.clone() for t in small)
+
+    def _forward(self, x, mode, out=None):
         B, N = x.shape[0], self.N
         sq = self.trunk.run(x, N)                                       # [5B,h,w,1024]: V | policy map
         pol_off = self.feat
         if getattr(self, "trunks5", None) is not None:                  # sq = the policy map alone [5B,h,w,512]
-            vcs_src = torch.cat([t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1) for i, t in enumerate(self.trunks5)], 0)
+            # five separate value encoders: five independent single-trunk chains -> five parallel branches (forked streams) instead of
+            # five chains one after the other
+            main = torch.cuda.current_stream(x.device)
+            parts = []
+            for i, t in enumerate(self.trunks5):
+                st = self.trunk._side_stream(x.device, 2 + i)
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    parts.append(t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1))
+            for i in range(len(self.trunks5)):
+                main.wait_stream(self.trunk._side_stream(x.device, 2 + i))
+                parts[i].record_stream(main)
+            vcs_src = torch.cat(parts, 0)
             pol_off = 0
         elif self.trunk0 is not None:
             v = sq[..., :self.feat].contiguous()
@@ -891,4 +938,4 @@ class SRMSEngine:
             coef5 = coef
         fused = ops.fuse_values(vcs_src, self.feat, coef5, B, N, 0, 1, append_own=self.who)
         low = self.decoder.low_logits(fused)
-        return ops.upsample_bilinear32(low, self.n_classes), prob, coef, action, nnz
+        return ops.upsample_bilinear32(low, self.n_classes, out=out), prob, coef, action, nnz

@@ -90,7 +90,7 @@ class _SRMSBase(_EngineCacheMixin, nn.Module):
     def _hip(self, inputs, mode):
         eng = self._engine_for(inputs, _engine.SRMSEngine)
         with torch.no_grad():
-            return eng.forward(inputs.contiguous().float(), mode)
+            return eng.forward(inputs.contiguous().float(), mode, use_graph=bool(getattr(self, "use_hip_graph", False)))
 
 
 class LearnWhen2Com(_SRMSBase):

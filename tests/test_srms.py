@@ -147,3 +147,32 @@ def test_hip_forward_matches_reference_vectors_and_oracle(case):
     # training=True is a return-shape flag (3-tuple, softmax fusion) under eval()
     res = model(x.cuda(), training=True)
     assert len(res) == 3 and res[1].shape == (b, 1, nk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_hip_graph_replay_of_the_single_request_forward_equals_eager(case):
+    """model.use_hip_graph on LearnWhen2Com / LearnWho2Com (round 4): the whole forward replays from one captured
+    graph per (shape, mode) -- static input copy, caller-owned logits through a pointer slot -- and must return the eager forward's
+    bits, on the capture input and on another input, with outputs that a later forward does not overwrite."""
+    from ptsemseg.models import get_model
+    model = get_model(_cfg(case), 11)
+    filler.apply_to_module(model)
+    model = model.to("cuda:0").eval()
+    b, s = case["batch"], case["size"]
+    xs = [torch.from_numpy(filler.synthetic_frames(b, 5, s, s, case["seed"] + k)).cuda() for k in range(2)]
+    mode = case["modes"][-1]
+    eager = [model(x, training=False, inference=mode) for x in xs]
+    model.use_hip_graph = True
+    keep = None
+    for x, ref in ((xs[0], eager[0]), (xs[1], eager[1]), (xs[0], eager[0])):
+        out = model(x, training=False, inference=mode)
+        assert len(out) == len(ref)
+        for a, r in zip(out, ref):
+            if torch.is_tensor(r):
+                assert torch.equal(a, r)
+            else:
+                assert a == r
+        if keep is None:
+            keep = (out[0], out[0].clone())
+    assert torch.equal(keep[0], keep[1])                   # caller-owned: later forwards did not touch the first result
