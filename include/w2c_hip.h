@@ -246,6 +246,24 @@ int w2c_bn_train_backward(const uint16_t* dy, const uint16_t* y_or_null, const u
                           uint16_t* dx, uint16_t* dres_or_null, float* dgamma, float* dbeta,
                           float* k123, void* workspace, long long workspace_bytes, w2c_stream_t stream);
 
+/* Two-phase forms of the same BatchNorm for AGENT-SHARDED training (round 4): the statistics run over the agent-concatenated batch
+ * (agent.py:1108-1111), so with the agents sharded over ranks the per-channel sums are added over the ranks between the phases.
+ *   w2c_bn_train_sums(mode, ...)  -> sums f64 [2][C]: mode 0 (sum x, sum x^2), mode 1 (sum dyr, sum dyr * xhat) of THIS rank's P pixels;
+ *   the caller all-reduces (SUM) the sums and the pixel count;
+ *   w2c_bn_train_forward_sums / _backward_sums finalize from the GLOBAL sums and P_total (dgamma / dbeta = this rank's own sums:
+ *   parameter gradients are all-reduced afterwards like every other gradient) and apply on the local pixels. */
+int w2c_bn_train_sums(int mode, const uint16_t* x, const uint16_t* dy, const uint16_t* y_or_null, const float* mean,
+                      const float* rstd, long long P, int C, double* sums, void* workspace, long long workspace_bytes,
+                      w2c_stream_t stream);
+int w2c_bn_train_forward_sums(const uint16_t* x, long long P, int C, const double* sums_global, double P_total,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              long long* num_batches_tracked_or_null, float momentum, float eps, const uint16_t* residual, int relu,
+                              uint16_t* y, float* mean, float* rstd, float* ab, w2c_stream_t stream);
+int w2c_bn_train_backward_sums(const uint16_t* dy, const uint16_t* y_or_null, const uint16_t* x, long long P, int C,
+                               const float* gamma, const float* mean, const float* rstd, const double* sums_local,
+                               const double* sums_global, double P_total, uint16_t* dx, uint16_t* dres_or_null,
+                               float* dgamma, float* dbeta, float* k123, w2c_stream_t stream);
+
 /* maxpool 3x3 s2 p1 for the training path (backbone.py:66): forward also records, per output element, the tap index 3*ky+kx of
  * the first maximum (idx u8 [M,H/2,W/2,C]); backward gathers dy over the <= 4 windows that selected each input element.
  * x, dx : bf16 NHWC [M,H,W,C]; y, dy : [M,H/2,W/2,C]; H, W even; C multiple of 8. */

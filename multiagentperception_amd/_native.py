@@ -54,6 +54,9 @@ SIGNATURES = {
     "w2c_bn_workspace_bytes": [_ll, _i],
     "w2c_bn_train_forward": [_vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
     "w2c_bn_train_backward": [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
+    "w2c_bn_train_sums": [_i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _ll, _vp],
+    "w2c_bn_train_forward_sums": [_vp, _ll, _i, _vp, _c.c_double, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "w2c_bn_train_backward_sums": [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _c.c_double, _vp, _vp, _vp, _vp, _vp, _vp],
     "w2c_maxpool3x3s2_train_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "w2c_maxpool3x3s2_train_backward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "w2c_debug_mx_mfma": [_vp, _vp, _vp, _vp],

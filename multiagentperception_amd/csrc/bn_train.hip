@@ -149,6 +149,59 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
+// ---- cross-rank (synchronised) BatchNorm, round 4: the two-phase forms.  Train-mode BatchNorm takes its statistics over the
+// agent-concatenated batch (agent.py:1108-1111); when the agents are sharded over ranks the per-channel sums must be added over the ranks
+// between the reduction and the finalize.  Phase A leaves the LOCAL sums as f64 [2][C] (+ the caller all-reduces them, with the pixel
+// count); phase B finalizes from the GLOBAL sums.
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ partial, int nchunk, int C, double* __restrict__ sums) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c < C) {
+        double s, q;
+        wave_sum2(partial, nchunk, C, c, s, q);
+        if ((threadIdx.x & 63) == 0) { sums[c] = s; sums[C + c] = q; }
+    }
+}
+__global__ __launch_bounds__(256) void bn_fwd_finalize_sums_kernel(const double* __restrict__ sums, double Ptot, int C, float eps, float momentum,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   long long* __restrict__ num_batches_tracked, float* __restrict__ mean,
+                                                                   float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ b) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / Ptot;
+    double var = sums[C + c] / Ptot - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    rstd[c] = r;
+    const float av = gamma[c] * r;
+    a[c] = av;
+    b[c] = beta[c] - (float)m * av;
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+    if (running_mean) {
+        const double unbiased = Ptot > 1.0 ? var * Ptot / (Ptot - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+// dgamma / dbeta are this rank's OWN sums (the parameter gradients are all-reduced with every other gradient afterwards); the three
+// constants of dx = k1*dyr + k2*x + k3 come from the GLOBAL sums and the global pixel count
+__global__ __launch_bounds__(256) void bn_bwd_finalize_sums_kernel(const double* __restrict__ loc, const double* __restrict__ glob, double Ptot,
+                                                                   int C, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
+                                                                   float* __restrict__ k3) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)loc[c];
+    dgamma[c] = (float)loc[C + c];
+    const double s = glob[c], q = glob[C + c];
+    const double A = (double)gamma[c] * rstd[c];
+    k1[c] = (float)A;
+    k2[c] = (float)(-A * rstd[c] * q / Ptot);
+    k3[c] = (float)(-A * s / Ptot + A * rstd[c] * mean[c] * q / Ptot);
+}
+
 // y = act(a*x + b (+ residual))
 __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ a,
                                                        const float* __restrict__ b, const uint16_t* __restrict__ res, int relu, long P,
@@ -352,5 +405,54 @@ extern "C" int w2c_maxpool3x3s2_train_backward(const uint16_t* dy, const uint8_t
     if (!dy || !dx || !idx || M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8)) return W2C_E_ARG;
     hipLaunchKernelGGL(maxpool_train_bwd_kernel, dim3(ew_grid((long)M * H * W * (C / 8))), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), dy, idx, M, H, W, C, dx);
+    return w2c_launch_status();
+}
+
+// ---- two-phase (cross-rank) forms: see bn_sums_kernel.  mode 0: sums = (sum x, sum x^2); mode 1: (sum dyr, sum dyr * xhat)
+extern "C" int w2c_bn_train_sums(int mode, const uint16_t* x, const uint16_t* dy, const uint16_t* y_or_null, const float* mean,
+                                 const float* rstd, long long P, int C, double* sums, void* workspace, long long workspace_bytes,
+                                 w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !sums || !workspace || P <= 0 || C <= 0 || (C % 8) || C > 2048 || (mode != 0 && mode != 1)) return W2C_E_ARG;
+    if (mode == 1 && (!dy || !mean || !rstd)) return W2C_E_ARG;
+    if (workspace_bytes < w2c_bn_workspace_bytes(P, C)) return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int ppc;
+    const int n = chunking(P, C, &ppc);
+    float* part = reinterpret_cast<float*>(workspace);
+    const size_t lds = (size_t)(256 / (C >> 3)) * 2 * C * 4;
+    if (mode == 0) hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(n), dim3(256), lds, s, x, nullptr, nullptr, nullptr, nullptr, (long)P, C, ppc, part);
+    else hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(n), dim3(256), lds, s, x, dy, y_or_null, mean, rstd, (long)P, C, ppc, part);
+    hipLaunchKernelGGL(bn_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, n, C, sums);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_bn_train_forward_sums(const uint16_t* x, long long P, int C, const double* sums_global, double P_total,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float momentum, float eps, const uint16_t* residual, int relu,
+                                         uint16_t* y, float* mean, float* rstd, float* ab, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!x || !sums_global || !gamma || !beta || !y || !mean || !rstd || !ab || P <= 0 || P_total < (double)P || C <= 0 || (C % 8) || C > 2048)
+        return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_fwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_global, P_total, C, eps, momentum, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, mean, rstd, ab, ab + C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(P * (C >> 3))), dim3(256), 0, s, x, ab, ab + C, residual, relu, (long)P, C, y);
+    return w2c_launch_status();
+}
+
+extern "C" int w2c_bn_train_backward_sums(const uint16_t* dy, const uint16_t* y_or_null, const uint16_t* x, long long P, int C,
+                                          const float* gamma, const float* mean, const float* rstd, const double* sums_local,
+                                          const double* sums_global, double P_total, uint16_t* dx, uint16_t* dres_or_null,
+                                          float* dgamma, float* dbeta, float* k123, w2c_stream_t stream) {
+    w2c_clear_error();
+    if (!dy || !x || !gamma || !mean || !rstd || !sums_local || !sums_global || !dx || !dgamma || !dbeta || !k123 || P <= 0 ||
+        P_total < (double)P || C <= 0 || (C % 8) || C > 2048)
+        return W2C_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_local, sums_global, P_total, C, gamma, mean, rstd,
+                       dgamma, dbeta, k123, k123 + C, k123 + 2 * C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(P * (C >> 3))), dim3(256), 0, s, dy, y_or_null, x, k123, k123 + C, k123 + 2 * C,
+                       (long)P, C, dx, dres_or_null);
     return w2c_launch_status();
 }

@@ -772,6 +772,61 @@ def bn_train_backward(dy, y, x, gamma, mean, rstd, want_dres=False):
     return dx, dres, g[0], g[1]
 
 
+def _allreduce_sums(sums_and_count, group):
+    """SUM over the ranks of [2C sums | pixel count] (f64), in place"""
+    import torch.distributed as dist
+    dist.all_reduce(sums_and_count, op=dist.ReduceOp.SUM, group=group)
+    return sums_and_count
+
+
+def bn_train_forward_sync(x, gamma, beta, running_mean, running_var, momentum, eps, group, residual=None, relu=True, out=None,
+                          num_batches_tracked=None):
+    """bn_train_forward with the statistics taken over EVERY rank's pixels (agent-sharded training: the reference's train-mode
+    BatchNorm runs over the agent-concatenated batch, agent.py:1108-1111): local sums (w2c_bn_train_sums) -> all-reduce of the 2C sums +
+    the pixel count -> finalize + apply from the global sums (w2c_bn_train_forward_sums).  -> (y, mean, rstd, P_total)."""
+    dev = _need_gpu(x, gamma, beta, running_mean, running_var, residual)
+    C = x.shape[-1]
+    P = x.numel() // C
+    if x.dtype != BF16 or (residual is not None and (residual.dtype != BF16 or residual.shape != x.shape)):
+        raise W2CError("bn: bf16 NHWC tensors expected")
+    y = torch.empty_like(x) if out is None else out
+    stats = torch.empty((4, C), dtype=torch.float32, device=dev)
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+    ws = _bn_workspace(dev, P, C)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_bn_train_sums(0, _p(x), 0, 0, 0, 0, P, C, _p(sums), _p(ws), ws.numel(), _stream(dev)), "w2c_bn_train_sums")
+    sums[2 * C] = float(P)
+    _allreduce_sums(sums, group)
+    p_total = float(sums[2 * C].item())            # (one host read per layer: the agent-sharded training step is not graph-captured)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_bn_train_forward_sums(_p(x), P, C, _p(sums), p_total, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                                      _p(num_batches_tracked), float(momentum), float(eps), _p(residual),
+                                                      1 if relu else 0, _p(y), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                      stats[2].data_ptr(), _stream(dev)), "w2c_bn_train_forward_sums")
+    return y, stats[0], stats[1], p_total
+
+
+def bn_train_backward_sync(dy, y, x, gamma, mean, rstd, p_total, group, want_dres=False):
+    """bn_train_backward with the two backward sums added over the ranks; dgamma / dbeta are THIS rank's contributions."""
+    dev = _need_gpu(dy, y, x, gamma, mean, rstd)
+    C = x.shape[-1]
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    g = torch.empty((5, C), dtype=torch.float32, device=dev)
+    loc = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    ws = _bn_workspace(dev, P, C)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_bn_train_sums(1, _p(x), _p(dy), _p(y), _p(mean), _p(rstd), P, C, _p(loc), _p(ws), ws.numel(), _stream(dev)),
+              "w2c_bn_train_sums")
+    glob = _allreduce_sums(loc.clone(), group)
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_bn_train_backward_sums(_p(dy), _p(y), _p(x), P, C, _p(gamma), _p(mean), _p(rstd), _p(loc), _p(glob),
+                                                       float(p_total), _p(dx), _p(dres), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                                       _stream(dev)), "w2c_bn_train_backward_sums")
+    return dx, dres, g[0], g[1]
+
+
 def linear(x, w, b, relu, x_stride=None, rows=None, k=None):
     """y[M,O] = act(x[M,K] W^T + b); x bf16 or f32 (2-D view given by rows/k/x_stride)."""
     dev = _need_gpu(x, w, b)

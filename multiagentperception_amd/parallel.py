@@ -367,3 +367,98 @@ class AgentParallelForward:
         self.last_exchange = (got, dense)
         pred, prob, action, nnz, _ = eng.graph_and_decode(v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, inference)
         return pred, prob, action, nnz
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Agent-sharded TRAINING step (round 4; SURVEY 8f rank 3 + 8e: "train-mode BN couples agents across ranks").  The reference trains
+# MIMOcom with every agent on one device (trainer.py:669-673); here rank r holds the frames of its own agents and
+#   * every train-mode BatchNorm takes its statistics over ALL ranks' pixels (train_ops.set_sync_bn: the reference normalises over the
+#     agent-concatenated batch, agent.py:1108-1111) -- forward sums and backward sums all-reduced between partial sums and finalize;
+#   * value maps and keys are all-gathered DIFFERENTIABLY (backward: the gradient contributions of every rank's loss, summed, this
+#     rank's rows), queries stay local, each rank fuses + decodes + takes the loss of its own query agents;
+#   * parameter gradients are all-reduced (SUM) in one flattened bucket: the global loss is the mean of the ranks' local losses, so
+#     every rank backpropagates local_loss / world.
+# The result equals the unsharded step up to summation order (tests/test_parallel_gpu.py: loss and gradients against the one-GPU step).
+class _AllGatherRows(torch.autograd.Function):
+    """y = concat over the ranks (rank order) of x along dim 0; dy -> sum over the ranks of dy, this rank's rows."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        world = dist.get_world_size(group)
+        ctx.group, ctx.rows, ctx.rank = group, x.shape[0], dist.get_rank(group)
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(_as_bytes_view(out), _as_bytes_view(x), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g[ctx.rank * ctx.rows:(ctx.rank + 1) * ctx.rows], None
+
+
+def agent_parallel_train_forward(model, inputs_local, group=None):
+    """Train-mode forward of MIMOcom / MIMOcomWho for this rank's agents (inputs_local f32 [B, 3*n_loc, H, W]) ->
+    (pred [n_loc*B, n_cls, H, W] with autograd history, prob [B, N, n_loc]).  Call under train_ops.set_sync_bn(True, group)."""
+    from . import train_ops
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    N = model.agent_num
+    q_lo, n_loc = shard_agents(N, world, rank)
+    B = inputs_local.shape[0]
+    unified = torch.cat([inputs_local[:, 3 * i:3 * i + 3] for i in range(n_loc)], 0)
+    if inputs_local.is_cuda and train_ops.bf16_activations():
+        unified = unified.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    feat = model.u_encoder(unified).float()
+    qk = model.query_key_net(unified)
+    keys = model.key_net(qk)
+    feat_all = _AllGatherRows.apply(feat, group)                       # agent-major rows of every agent (rank order = agent order)
+    keys_all = _AllGatherRows.apply(keys, group)
+    val_mat = torch.stack([feat_all[B * i:B * (i + 1)] for i in range(N)], 1)
+    key_mat = torch.stack([keys_all[B * i:B * (i + 1)] for i in range(N)], 1)
+    if model.has_query:
+        qs = model.query_net(qk)
+        query_mat = torch.stack([qs[B * i:B * (i + 1)] for i in range(n_loc)], 1)
+    else:
+        query_mat = torch.ones(B, n_loc, model.query_size, device=inputs_local.device)
+    scores = torch.bmm(key_mat, model.attention_net.linear(query_mat).transpose(2, 1))        # [B, N keys, n_loc queries]
+    who = bool(getattr(model, "_who", False))
+    if who:
+        mask = torch.zeros(N, n_loc, dtype=torch.bool, device=inputs_local.device)
+        mask[torch.arange(q_lo, q_lo + n_loc), torch.arange(n_loc)] = True
+        scores = scores.masked_fill(mask.unsqueeze(0), float("-inf"))
+    prob = torch.softmax(scores, dim=1)
+    fused = torch.einsum("bkq,bkchw->bqchw", prob, val_mat)
+    if who:
+        fused = torch.cat((fused, val_mat[:, q_lo:q_lo + n_loc]), dim=2)
+    pred = model.decoder(torch.cat([fused[:, i] for i in range(n_loc)], 0))
+    return pred, prob
+
+
+def agent_parallel_train_step(model, optimizer, loss_fn, inputs_local, labels_local, group=None):
+    """One agent-sharded training step (see the block comment above) -> the GLOBAL loss (mean over the ranks) as a float tensor.
+    labels_local: the labels of this rank's agents, agent-major [n_loc*B, H, W]."""
+    from . import train_ops
+    world = dist.get_world_size(group)
+    train_ops.set_sync_bn(True, group)
+    try:
+        optimizer.zero_grad(set_to_none=True)
+        pred, _ = agent_parallel_train_forward(model, inputs_local, group)
+        loss = loss_fn(pred, labels_local)
+        (loss / world).backward()
+    finally:
+        train_ops.set_sync_bn(False)
+    params = [p for p in model.parameters() if p.grad is not None]
+    if params:
+        flat = torch.cat([p.grad.reshape(-1).float() for p in params])         # one bucket: one collective
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    optimizer.step()
+    g = loss.detach().clone().float()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return g / world

@@ -212,10 +212,22 @@ def upsample32(y):
     return F.interpolate(y.float(), size=(y.shape[2] * 32, y.shape[3] * 32), mode="bilinear", align_corners=False)
 
 
+_sync_bn_group = None          # None: local statistics; otherwise (group,): statistics over every rank of `group` (None = the world)
+
+
+def set_sync_bn(enabled, group=None):
+    """Agent-sharded training (round 4): train-mode BatchNorm statistics over EVERY rank's pixels -- the reference normalises over the
+    agent-concatenated batch (agent.py:1108-1111), so ranks that each hold some of the agents must add their per-channel sums.
+    set_sync_bn(True[, group]) / set_sync_bn(False).  Needs an initialised process group."""
+    global _sync_bn_group
+    _sync_bn_group = (group,) if enabled else None
+
+
 class _BnActFn(torch.autograd.Function):
     """train-mode BatchNorm2d + (residual add) + (ReLU) as one fused forward and one fused backward on the HIP kernels
     (w2c_bn_train_forward / _backward): 3 + 3 streaming launches instead of MIOpen's 3 + 3 plus separate add / ReLU /
-    threshold-backward kernels, deterministic reductions."""
+    threshold-backward kernels, deterministic reductions.  With set_sync_bn the two reductions are all-reduced over the ranks
+    between their partial sums and their finalize (ops.bn_train_forward_sync / _backward_sync)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, nbt=None):
@@ -223,8 +235,14 @@ class _BnActFn(torch.autograd.Function):
         rh = None if residual is None else _nhwc_bf16(residual)
         M, H, W, C = xh.shape
         y = torch.empty((M, C, H, W), dtype=BF16, device=x.device, memory_format=torch.channels_last)   # not a view (see _Conv2dHipFn)
-        _, mean, rstd = ops.bn_train_forward(xh, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
-                                             residual=rh, relu=relu, out=y.permute(0, 2, 3, 1), num_batches_tracked=nbt)
+        ctx.sync = _sync_bn_group
+        if ctx.sync is not None:
+            _, mean, rstd, ctx.p_total = ops.bn_train_forward_sync(xh, gamma.detach(), beta.detach(), running_mean, running_var, momentum,
+                                                                    eps, ctx.sync[0], residual=rh, relu=relu, out=y.permute(0, 2, 3, 1),
+                                                                    num_batches_tracked=nbt)
+        else:
+            _, mean, rstd = ops.bn_train_forward(xh, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
+                                                 residual=rh, relu=relu, out=y.permute(0, 2, 3, 1), num_batches_tracked=nbt)
         ctx.save_for_backward(xh, y if relu else None, gamma, mean, rstd)
         ctx.has_res = residual is not None
         ctx.res_dtype = None if residual is None else residual.dtype
@@ -235,7 +253,11 @@ class _BnActFn(torch.autograd.Function):
         xh, y, gamma, mean, rstd = ctx.saved_tensors
         yh = None if y is None else y.permute(0, 2, 3, 1)
         gyh = _nhwc_bf16(gy)
-        dx, dres, dgamma, dbeta = ops.bn_train_backward(gyh, yh, xh, gamma.detach(), mean, rstd, want_dres=ctx.has_res)
+        if ctx.sync is not None:
+            dx, dres, dgamma, dbeta = ops.bn_train_backward_sync(gyh, yh, xh, gamma.detach(), mean, rstd, ctx.p_total, ctx.sync[0],
+                                                                 want_dres=ctx.has_res)
+        else:
+            dx, dres, dgamma, dbeta = ops.bn_train_backward(gyh, yh, xh, gamma.detach(), mean, rstd, want_dres=ctx.has_res)
         dxo = dx.permute(0, 3, 1, 2)
         dro = None
         if dres is not None:
