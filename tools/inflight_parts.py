@@ -106,4 +106,6 @@ check("V1 convs on side + heads (product)", lambda e, a: flat(e.trunk.after_stem
 check("V2 host sync of side before heads", v_sync, [s0] * F)
 check("V3 heads enqueued after after_stem", v_late, [s0] * F)
 check("V4 policy convs + heads on main", v_mainconvs, [s0] * F)
-check("graph_and_low", lambda e, a: e.graph_and_low(a, kq[0], kq[1] if len(kq) > 1 else None, B, n, 0, n, "softmax"), [sq] * F)
+# (round 4: graph_and_low fuses the U maps = the decoder's first conv of the value maps, engine.DecoderPlan.value_maps)
+ucheck = check("value_maps (decoder conv0 on V)", lambda e, a: e.value_maps(a), [sq] * F)[0]
+check("graph_and_low", lambda e, a: e.graph_and_low(a, kq[0], kq[1] if len(kq) > 1 else None, B, n, 0, n, "softmax"), [ucheck] * F)
