@@ -183,8 +183,24 @@ int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int W, int Cin,
                       uint16_t* idt_bf16, int idt_cstride,
                       const void* zero_page, int variant, w2c_stream_t stream);
 
+/* ---- the same block front on the weights-to-registers structure (csrc/conv_s2wreg.inl; round 4): bf16 only, maps whose OUTPUT
+ * tiles into 8 x 16 pixels (H, W even, (H/2) % 8 == 0, (W/2) % 16 == 0), Cin in {64, 128, 192, 256}, Cout % 64 == 0 --
+ * w2c_conv_s2_block_wreg_supported() says whether the library offers it for a geometry (a function of the geometry only, never
+ * of M or the group count, so a sharded batch takes the same kernel as the whole one).
+ * w3frag : conv1's weights in w2c_pack_wfrag_bf16 order; w1frag : the 1x1 downsample's weights [groups][Cout][Cin] in the same
+ * fragment order with ONE tap: [groups][Cout/32][Cin/64][k slice 0..3][half][channel % 32][8] (ops.pack_w1frag).
+ * t = relu(conv1 * scale3 + shift3): sums K in per-K-group partial sums (equal to w2c_conv_s2_block's t to f32 rounding, not bit
+ * for bit); idt is bit-identical to w2c_conv_s2_block's.  form 0 = the library's choice (1..4: A/B forms).  The next-call debug
+ * hooks of w2c_conv_s2_block (span) apply. */
+int w2c_conv_s2_block_wreg_supported(int H, int W, int Cin, int Cout);
+int w2c_conv_s2_block_wreg(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                           const uint16_t* w3frag, const float* scale3, const float* shift3,
+                           const uint16_t* w1frag, const float* scale1, const float* shift1,
+                           int Cout, int groups, uint16_t* t_bf16, int t_cstride, uint16_t* idt_bf16, int idt_cstride,
+                           int form, w2c_stream_t stream);
+
 /* ---- debug / A-B switches ("W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND", "W2C_STEM_WAVES",
- * "W2C_WGRAD_PATCH").  The library reads the environment variables of the same names ONCE, when it is loaded; no launch path calls
+ * "W2C_WGRAD_PATCH", ... "W2C_S2WREG_FORM": csrc/w2c_common.h lists them all).  The library reads the environment variables of the same names ONCE, when it is loaded; no launch path calls
  * getenv().  w2c_set_option changes a switch at run time (returns W2C_E_ARG for an unknown name), w2c_get_option reads it (-1 unknown). */
 int w2c_set_option(const char* name, int value);
 int w2c_get_option(const char* name);

@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 0};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -1926,6 +1926,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
 
 #include "conv_wreg.inl"
 #include "conv_regh.inl"
+#include "conv_s2wreg.inl"
 
 template <int BM, int BN, int BK, int STAGES>
 constexpr int conv_lds_bytes() {
@@ -2585,6 +2586,8 @@ extern "C" int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int 
     if (rc != W2C_OK) return rc;
     if (!w1 || !scale1 || !shift1 || !idt_bf16 || idt_cstride < groups * Cout || (idt_cstride % 8) != 0) return W2C_E_ARG;
     a.w2 = reinterpret_cast<const uint16_t*>(w1); a.scale2 = scale1; a.shift2 = shift1; a.y2 = idt_bf16; a.y2cs = idt_cstride;
+    a.dbg = g_dbg_next;
+    g_dbg_next = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // maps that tile into 8 x 16 output pixels go to the polyphase halo-patch kernel (variant 60), the rest to the generic
     // DUAL kernel; both walk K in the same order, so the choice never shows in the bits
@@ -2594,6 +2597,48 @@ extern "C" int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int 
     if (variant == 61) return x_is_fp8 ? launch_s2patch<128, 2, true>(a, groups, s) : launch_s2patch<128, 2, false>(a, groups, s);
     if (variant == 62) return x_is_fp8 ? launch_s2patch<64, 2, true>(a, groups, s) : launch_s2patch<64, 2, false>(a, groups, s);
     return x_is_fp8 ? launch_dual<true>(a, groups, variant, s) : launch_dual<false>(a, groups, variant, s);
+}
+
+// Stride-2 block front on the weights-to-registers structure (conv_s2wreg.inl).  A function of the layer geometry only.
+// NOT offered by default (W2C_S2WREG_FORM=1 turns it on): alone it beats the polyphase ring kernel on layer3.0 / layer4.0 (cfg 2, one
+// group: 26.0 vs 29.5, 25.0 vs 29.5 us; layer2.0 32.1 vs 32.6) but its workgroups live as long (prologue 2.5-3 us + reduction +
+// downsample pass + stores around a main loop that is 1.3-1.7x faster), so beside the other trunk chain the forward does not move
+// (1.0484 vs 1.0485 ms, 3 interleaved pairs; rank shapes of cfg 3 / cfg 4 the same) -- profiles/r04_s2_front_wreg.txt.
+static int s2wreg_form(int H, int W, int Cin, int Cout) {
+    if (H <= 0 || W <= 0 || (H & 1) || (W & 1) || ((H / 2) % 8) != 0 || ((W / 2) % 16) != 0 || (Cin % 64) != 0 || Cin > 256 || (Cout % 64) != 0)
+        return 0;
+    const int f = w2c_option(W2C_OPT_S2WREG_FORM);
+    if (f == 3 && (Cout % 128) != 0) return 1;
+    return (f >= 1 && f <= 4) ? f : 0;
+}
+extern "C" int w2c_conv_s2_block_wreg_supported(int H, int W, int Cin, int Cout) { return s2wreg_form(H, W, Cin, Cout) != 0; }
+
+extern "C" int w2c_conv_s2_block_wreg(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                      const uint16_t* w3frag, const float* scale3, const float* shift3,
+                                      const uint16_t* w1frag, const float* scale1, const float* shift1,
+                                      int Cout, int groups, uint16_t* t_bf16, int t_cstride, uint16_t* idt_bf16, int idt_cstride,
+                                      int form, w2c_stream_t stream) {
+    w2c_clear_error();
+    ConvArgs a;
+    const int rc = fill_args(a, x, M, H, W, Cin, x_cstride, w3frag, Cout, 3, 2, groups, scale3, shift3, nullptr, 1, t_bf16, t_cstride, 0,
+                             /*zero_page=*/x, 0);
+    if (rc != W2C_OK) return rc;
+    if (!t_bf16 || !w1frag || !scale1 || !shift1 || !idt_bf16 || idt_cstride < groups * Cout || (idt_cstride % 8) != 0) return W2C_E_ARG;
+    // 32-bit element offsets in the epilogue
+    if ((size_t)M * a.Ho * a.Wo * t_cstride >= (1ull << 31) || (size_t)M * a.Ho * a.Wo * idt_cstride >= (1ull << 31)) return W2C_E_ARG;
+    a.w2 = w1frag; a.scale2 = scale1; a.shift2 = shift1; a.y2 = idt_bf16; a.y2cs = idt_cstride;
+    a.dbg = g_dbg_next;
+    g_dbg_next = nullptr;
+    if (form == 0) form = s2wreg_form(H, W, Cin, Cout);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (form >= 16) { a.n_split = form >> 4; form &= 15; }      // (debug: which point the timeline's third stamp marks)
+    switch (form) {
+        case 1: return launch_s2wreg<1, 4, 4>(a, groups, s);
+        case 2: return launch_s2wreg<1, 4, 2>(a, groups, s);
+        case 3: return launch_s2wreg<2, 2, 2>(a, groups, s);
+        case 4: return launch_s2wreg<1, 2, 2>(a, groups, s);
+        default: return W2C_E_ARG;
+    }
 }
 
 // One wave: C[32][32] (f32, row-major) = A[32][64] * B[32][64]^T with e4m3 operands through the MX-scaled MFMA with unit

@@ -93,6 +93,15 @@ class ConvPlan:
         if (_USE_WREG and self.ksize == 3 and self.stride == 1 and self.cin % 64 == 0 and self.cout % 64 == 0 and self.w.is_cuda
                 and ops.conv3x3_wreg_supported(8, 16, self.cin, self.cout)):
             self.wfrag = ops.pack_wfrag_device(self.w, self.cin)
+        # the two convs of a stride-2 block front keep fragment-ordered copies for w2c_conv_s2_block_wreg (same rule: the library
+        # decides from the geometry, _block_front asks it)
+        self.wfrag_s2 = None
+        if (_USE_WREG and self.stride == 2 and self.cin % 64 == 0 and self.cin <= 256 and self.cout % 64 == 0 and self.w.is_cuda
+                and ops.conv_s2_block_wreg_supported(16, 32, self.cin, self.cout)):
+            if self.ksize == 3:
+                self.wfrag_s2 = ops.pack_wfrag_device(self.w, self.cin)
+            elif self.ksize == 1:
+                self.wfrag_s2 = ops.pack_w1frag(self.w, self.cin)
 
     def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None, out=None, out_ch_off=0):
         far = False                                  # group slabs further apart than the kernel's 32-bit output offsets reach
@@ -165,6 +174,10 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
             return (c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1],
                     ds.run(x, x_ch_off=x_ch_off)[0])
         return c1.run(x, x_ch_off=x_ch_off), ds.run(x, x_ch_off=x_ch_off)
+    if (not f8 and getattr(c1, "wfrag_s2", None) is not None and getattr(ds, "wfrag_s2", None) is not None
+            and ops.conv_s2_block_wreg_supported(x.shape[1], x.shape[2], c1.cin, c1.cout)):
+        return ops.conv_s2_block_wreg(x, x_ch_off, c1.cin, c1.wfrag_s2, c1.scale, c1.shift, ds.wfrag_s2, ds.scale, ds.shift,
+                                      c1.cout, c1.groups)
     t16, t8, idt = ops.conv_s2_block(x, x_ch_off, c1.cin, c1.w, c1.scale, c1.shift, ds.w, ds.scale, ds.shift, c1.cout,
                                      c1.groups, t_bf16=not f8, t_fp8_scale=t_fp8_scale)
     return (t8 if f8 else t16), idt

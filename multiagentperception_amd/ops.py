@@ -563,6 +563,48 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
     return t16, t8, idt
 
 
+def pack_w1frag(w1, cin):
+    """[G, Cout, cin] bf16 weights of a 1x1 conv -> MFMA A-fragment order with one tap (include/w2c_hip.h, w2c_conv_s2_block_wreg):
+    [G][Cout/32][cin/64][k slice 0..3][half][channel % 32][8].  Same bytes, permuted (plan-build time)."""
+    G, cout, K = w1.shape
+    if K != cin or cin % 64 or cout % 32:
+        raise W2CError("pack_w1frag: needs a 1x1 conv with cin % 64 == 0 and cout % 32 == 0")
+    v = w1.reshape(G, cout // 32, 32, cin // 64, 4, 2, 8)              # g, nb, c32, cc, kk, half, e
+    return v.permute(0, 1, 3, 4, 5, 2, 6).contiguous().reshape(G, cout, K)
+
+
+def conv_s2_block_wreg_supported(H, W, cin, cout):
+    return bool(_native.lib().w2c_conv_s2_block_wreg_supported(int(H), int(W), int(cin), int(cout)))
+
+
+def conv_s2_block_wreg(x, x_ch_off, cin, w3frag, scale3, shift3, w1frag, scale1, shift1, cout, groups, form=0):
+    """Front of a stride-2 BasicBlock on the weights-to-registers kernel (include/w2c_hip.h w2c_conv_s2_block_wreg): returns
+    (t bf16, idt bf16).  x bf16 NHWC; w3frag from pack_wfrag_device, w1frag from pack_w1frag."""
+    dev = _need_gpu(x, w3frag, scale3, shift3, w1frag, scale1, shift1)
+    if x.dtype != BF16 or w3frag.dtype != BF16 or w1frag.dtype != BF16:
+        raise W2CError("conv_s2_block_wreg: bf16 operands")
+    M, H, W, xcs = x.shape
+    if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
+        raise W2CError("conv_s2_block_wreg: channels outside the tensor")
+    if tuple(w3frag.shape) != (groups, cout, 9 * cin) or tuple(w1frag.shape) != (groups, cout, cin):
+        raise W2CError("conv_s2_block_wreg: weight shapes")
+    Ho, Wo = H // 2, W // 2
+    t16 = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    idt = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    timer = getattr(_tls, "conv_timer", None)
+    tok = timer.begin(dev) if timer is not None else None
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_s2_block_wreg(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(w3frag), _p(scale3), _p(shift3),
+                                                   _p(w1frag), _p(scale1), _p(shift1), cout, groups, _p(t16), groups * cout,
+                                                   _p(idt), groups * cout, int(form), _stream(dev)),
+              "w2c_conv_s2_block_wreg")
+    if timer is not None:
+        flops = 2.0 * M * Ho * Wo * cout * (10 * cin) * groups
+        nbytes = M * H * W * cin * groups * 2 + M * Ho * Wo * cout * groups * 4 + groups * cout * 10 * cin * 2
+        timer.end(tok, dev, flops, (M * Ho * Wo, cin, cout, "3+1", 2, groups), nbytes)
+    return t16, idt
+
+
 def conv_block_c64(x, w1, scale1, shift1, w2, scale2, shift2, groups, out=None, max_workgroups=0):
     """A whole 64-channel stride-1 BasicBlock in one launch (include/w2c_hip.h w2c_conv_block_c64):
     y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).  x bf16 NHWC [M,H,W,cs], group g in channels [64g, 64g+64);

@@ -21,7 +21,9 @@ import os
 import torch
 import torch.distributed as dist
 
-_ONE_GRAPH = os.environ.get("W2C_SHARD_ONE_GRAPH", "1") != "0"     # the sharded softmax step as one captured graph (nccl backend only)
+_ONE_GRAPH = os.environ.get("W2C_SHARD_ONE_GRAPH", "1") != "0"     # the sharded step as one captured graph (nccl backend only)
+_SPARSE_FORCE = {"1": True, "0": False}.get(os.environ.get("W2C_SHARD_SPARSE", ""))        # see AgentParallelForward._sparse_pays
+_SPARSE_MIN_BYTES = int(float(os.environ.get("W2C_SHARD_SPARSE_MIN_MB", "8")) * (1 << 20))
 
 
 def _as_bytes_view(t):
@@ -223,10 +225,10 @@ class AgentParallelForward:
             x = inputs_local.contiguous().float()
             if self.world == 1 and not (self.force_sharded and dist.is_initialized()):
                 return eng.forward_local(x, B, N, inference, use_graph=use_graph)
-            if (inference == "softmax" and use_graph and _ONE_GRAPH and not eng.trunk.n8 and self._one_graph_ok
-                    and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+            if ((inference == "softmax" or not self._sparse_pays(eng, x)) and use_graph and _ONE_GRAPH and not eng.trunk.n8
+                    and self._one_graph_ok and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
                 try:
-                    return self._softmax_one_graph(eng, x, B, N)
+                    return self._one_graph(eng, x, B, N, inference)
                 except RuntimeError as e:       # capture refused (an RCCL build that cannot be captured): the segment form below
                     import warnings
                     warnings.warn("agent-parallel forward: one-graph capture failed (%s); using 3 graph segments + eager collectives" % (e,))
@@ -249,8 +251,24 @@ class AgentParallelForward:
             prob, action, nnz = prob.clone(), action.clone(), nnz.clone()
         return pred, prob, action, nnz
 
-    def _softmax_one_graph(self, eng, x, B, N):
-        """The whole sharded 'softmax' step of a rank as ONE captured HIP graph (round 4), RCCL all-gathers included:
+    def _sparse_pays(self, eng, x):
+        """'activated' / 'argmax_test' across ranks: handshake-ordered sparse exchange (self._sparse: only the maps with a non-zero
+        fusion weight cross the links, but the transfer sizes are host arguments of the all-to-all -- one host round trip, eager
+        launches behind it) or the dense all-gather inside the one-graph step (every map crosses, nothing leaves the device)?
+        The dense step costs the unused maps' bytes, the sparse one ~0.1 ms of host round trip + eager launches: dense below
+        W2C_SHARD_SPARSE_MIN_MB (default 8) MiB of maps received per rank and step -- every BASELINE config (cfg 2: 4.2 MB) -- sparse
+        above.  W2C_SHARD_SPARSE=1 / 0 forces one."""
+        if _SPARSE_FORCE is not None:
+            return _SPARSE_FORCE
+        B, _, H, W = x.shape
+        ucs = 512 if eng.who else 256
+        recv = (self.world - 1) * self.n_loc * B * (H // 32) * (W // 32) * ucs * 4
+        return recv >= _SPARSE_MIN_BYTES
+
+    def _one_graph(self, eng, x, B, N, inference):
+        """The whole sharded step of a rank as ONE captured HIP graph (round 4), RCCL all-gathers included ('softmax'; 'activated' /
+        'argmax_test' when the dense exchange is the cheaper one, see _sparse_pays -- the communication-graph kernel zeroes the
+        coefficients of the unused maps either way, so the results equal the sparse path's bit for bit):
             stem (reads the caller's frames through a pointer slot) -> layer1 (both trunks) -> fork
               value chain : layer2..4, squeezer, decoder conv0 on the local value maps (U, into this rank's rows of the gather buffer),
                             in-place all-gather of U  -- issued from the value chain, so it travels under the policy chain's tail
@@ -265,7 +283,7 @@ class AgentParallelForward:
         dev = x.device
         H, W = x.shape[2], x.shape[3]
         out = torch.empty((n_loc * B, eng.n_classes, H, W), dtype=torch.float32, device=dev)
-        ent = st.graphs.get("whole")
+        ent = st.graphs.get("whole:" + inference)
         if ent is None:
             slots = torch.zeros(8, dtype=torch.int64, device=dev)
             xs = ops.SlotRef(slots, 0, x)
@@ -291,7 +309,7 @@ class AgentParallelForward:
                 for wk in works:
                     exchange_wait(wk)
                 pack2 = ops.SlotRef(slots, 2, ops.graph_outputs(dev, B, N, n_loc)[0])
-                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, "softmax", pack2=pack2)
+                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=pack2)
                 pack = eng._last_pack
                 ops.upsample_bilinear32(low, eng.n_classes, out=outs)
                 return pack
@@ -308,12 +326,14 @@ class AgentParallelForward:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 pack = whole()
-            ent = st.graphs["whole"] = (graph, slots, pack)
+            ent = st.graphs["whole:" + inference] = (graph, slots, pack)
         graph, slots, pack = ent
         packc = torch.empty_like(pack)
         ops.set_slots(slots, [x, out, packc])
         graph.replay()
         self.launch_form = "one hip-graph incl. the RCCL all-gathers"
+        dense = (self.world - 1) * n_loc * B
+        self.last_exchange = (dense, dense)
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
         return out, prob, action, nnz
 

@@ -1137,6 +1137,77 @@ def test_conv3x3_wreg_is_independent_of_the_image_count_and_repeatable():
             assert torch.equal(again, full)
 
 
+S2W_CASES = [
+    # (form, M, H, W, cin, cout, G, x channel pad)
+    (1, 3, 32, 64, 64, 128, 1, 0),       # layer2.0: one chunk; 2 x 2 tiles (top / left halo and interior tiles)
+    (1, 2, 32, 64, 128, 256, 2, 64),     # layer3.0: two chunks, two groups, x wider than the conv reads
+    (1, 2, 16, 32, 256, 512, 1, 0),      # layer4.0: four chunks
+    (1, 1, 16, 64, 192, 64, 1, 0),       # odd chunk count (the statically-last chunk body)
+    (2, 2, 32, 64, 128, 128, 2, 0),
+    (3, 2, 32, 64, 128, 256, 1, 0),
+    (3, 3, 32, 64, 64, 128, 2, 0),
+    (4, 2, 16, 32, 256, 128, 1, 0),
+]
+
+
+def _s2w_setup(case, seed):
+    form, M, H, W, cin, cout, G, xpad = case
+    gen = torch.Generator().manual_seed(seed)
+    x = (torch.randn(M, H, W, G * cin + xpad, generator=gen)).to(BF16)
+    w3 = (torch.randn(G, cout, 9 * cin, generator=gen) * (1.5 / (9 * cin) ** 0.5)).to(BF16)
+    w1 = (torch.randn(G, cout, cin, generator=gen) * (1.5 / cin ** 0.5)).to(BF16)
+    sc3 = torch.rand(G * cout, generator=gen) + 0.5
+    sh3 = torch.randn(G * cout, generator=gen) * 0.3
+    sc1 = torch.rand(G * cout, generator=gen) + 0.5
+    sh1 = torch.randn(G * cout, generator=gen) * 0.3
+    return [t.to(_dev()) for t in (x, w3, w1, sc3, sh3, sc1, sh1)]
+
+
+@pytest.mark.parametrize("case", S2W_CASES, ids=lambda c: "f%d-m%d-%dx%d-c%d-%d-g%d" % c[:7])
+def test_s2_block_front_on_the_wreg_structure_matches_the_ring_kernel_and_fp32(case):
+    """w2c_conv_s2_block_wreg (csrc/conv_s2wreg.inl): the downsample output is bit-identical to the polyphase ring kernel's (same MFMA
+    sequence per output), conv1 within one bf16 ulp of it (per-K-group partial sums) and within the usual bound of an fp32 conv."""
+    from multiagentperception_amd import ops
+    form, M, H, W, cin, cout, G, xpad = case
+    x, w3, w1, sc3, sh3, sc1, sh1 = _s2w_setup(case, 1000 + sum(case))
+    t, idt = ops.conv_s2_block_wreg(x, 0, cin, ops.pack_wfrag_device(w3, cin), sc3, sh3, ops.pack_w1frag(w1, cin), sc1, sh1, cout, G,
+                                    form=form)
+    t0, _, idt0 = ops.conv_s2_block(x, 0, cin, w3, sc3, sh3, w1, sc1, sh1, cout, G)
+    torch.cuda.synchronize()
+    assert torch.equal(idt, idt0)
+    d = (t.float() - t0.float()).abs()
+    assert float((d / (t0.float().abs() + 1.0)).max()) <= 2 ** -7
+    assert float((d > 0).float().mean()) < 0.2          # (most outputs round to the same bf16)
+    xc, w3c = x.float().cpu(), w3.float().cpu()
+    for g in range(G):
+        xin = xc[..., g * cin:(g + 1) * cin].permute(0, 3, 1, 2)
+        wg = w3c[g].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        ref = F.conv2d(xin, wg, None, stride=2, padding=1)
+        ref = F.relu(ref * sc3.cpu()[g * cout:(g + 1) * cout].view(1, -1, 1, 1) + sh3.cpu()[g * cout:(g + 1) * cout].view(1, -1, 1, 1))
+        np.testing.assert_allclose(_to_nchw(t, g * cout, cout).numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
+
+
+def test_s2_block_front_wreg_is_independent_of_image_count_and_groups_and_repeatable():
+    """one workgroup per 8 x 16 output tile, fixed summation order: image i of a batch equals that image run alone, group g of a
+    two-group launch equals the one-group launch, 40 repeats are identical (race screen for the phase-buffer hand-offs, the exchange
+    area and the second pass's re-staging)."""
+    from multiagentperception_amd import ops
+    for form, cin, cout, H, W in ((1, 128, 256, 32, 64), (1, 256, 128, 16, 64), (3, 64, 128, 32, 64), (4, 128, 64, 32, 32)):
+        case = (form, 5, H, W, cin, cout, 2, 0)
+        x, w3, w1, sc3, sh3, sc1, sh1 = _s2w_setup(case, 7 + form + cin)
+        f3, f1 = ops.pack_wfrag_device(w3, cin), ops.pack_w1frag(w1, cin)
+        t, idt = [o.clone() for o in ops.conv_s2_block_wreg(x, 0, cin, f3, sc3, sh3, f1, sc1, sh1, cout, 2, form=form)]
+        for i in (0, 4):
+            t1, i1 = ops.conv_s2_block_wreg(x[i:i + 1].contiguous(), 0, cin, f3, sc3, sh3, f1, sc1, sh1, cout, 2, form=form)
+            assert torch.equal(t1[0], t[i]) and torch.equal(i1[0], idt[i])
+        tg, ig = ops.conv_s2_block_wreg(x, cin, cin, f3[1:].contiguous(), sc3[cout:].contiguous(), sh3[cout:].contiguous(),
+                                        f1[1:].contiguous(), sc1[cout:].contiguous(), sh1[cout:].contiguous(), cout, 1, form=form)
+        assert torch.equal(tg, t[..., cout:]) and torch.equal(ig, idt[..., cout:])
+        for _ in range(40):
+            t2, i2 = ops.conv_s2_block_wreg(x, 0, cin, f3, sc3, sh3, f1, sc1, sh1, cout, 2, form=form)
+            assert torch.equal(t2, t) and torch.equal(i2, idt)
+
+
 def test_conv3x3_wreg_xcd_placement_leaves_results_bit_identical(lib_option):
     """W2C_XCD2D only changes which workgroup computes which tile"""
     from multiagentperception_amd import ops

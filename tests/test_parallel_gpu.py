@@ -124,6 +124,51 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
     assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
 
 
+def _rccl_one_rank_worker(rank, port, N, B, S, seed, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)          # a hung collective must not hold the GPU box
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from oracle import filler
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import parallel
+    model = get_model(_cfg(N, S), 11)
+    filler.apply_to_module(model)
+    model = model.to("cuda:0").eval()
+    model.use_hip_graph = True
+    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed)).cuda()
+    other = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed + 1)).cuda()
+    res = {}
+    for mode in ("activated", "argmax_test", "softmax"):
+        ref = [t.clone() for t in model(x, training=False, MO_flag=True, inference=mode)[:3]]
+        for sparse in (False, True):
+            parallel._SPARSE_FORCE = sparse
+            fwd = parallel.AgentParallelForward(model)
+            fwd.force_sharded = True
+            fwd(other, inference=mode)                             # capture on other frames: the checked call is a pure replay
+            out = fwd(x, inference=mode)
+            torch.cuda.synchronize()
+            res[(mode, sparse)] = (all(torch.equal(a, b) for a, b in zip(out[:3], ref)), fwd.launch_form, fwd.last_exchange
+                                   if mode != "softmax" else None)
+    torch.save(res, os.path.join(out_dir, "res.pt"))
+    dist.destroy_process_group()
+
+
+def test_thresholded_modes_through_the_one_graph_sharded_step_equal_the_plain_forward(tmp_path):
+    """'activated' / 'argmax_test' across ranks without the handshake's host round trip (parallel._sparse_pays): the dense in-graph
+    all-gather + the communication-graph kernel's zero coefficients give the same bits as the plain forward and as the sparse
+    exchange; the step is ONE captured graph with the RCCL collectives inside.  One rank (RCCL refuses two on one GPU)."""
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), 4, 2, 128, 555, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "res.pt"))
+    for (mode, sparse), (same, form, exch) in res.items():
+        assert same, (mode, sparse, form)
+        if mode == "softmax" or not sparse:
+            assert "one hip-graph" in form, (mode, sparse, form)
+        else:
+            assert "segments" in form, (mode, sparse, form)
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_two_rank_fp8_trunk_quantises_alike_on_every_rank(tmp_path, graph):
     """fp8 value encoder, sharded: the calibration amax is all-reduced (MAX) over the ranks, so every rank uses the scales the

@@ -27,4 +27,8 @@ for name, hw, cin, cout in (("l2.0", 128, 64, 128), ("l3.0", 64, 128, 256), ("l4
         line += "  dual v%d %.1f" % (v, t(lambda: ops.conv_s2_block(x, 0, cin, w3, sc, sh, w1, sc, sh, cout, G, variant=v)))
     for v in (3, 60, 61, 62):
         line += "  3x3 v%d %.1f" % (v, t(lambda: ops.conv_igemm(x, 0, cin, w3, cout, 3, 2, G, sc, sh, variant=v)))
+    if ops.conv_s2_block_wreg_supported(hw, hw, cin, cout):
+        f3, f1 = ops.pack_wfrag_device(w3, cin), ops.pack_w1frag(w1, cin)
+        for form in (1, 2, 3, 4):
+            line += "  wreg f%d %.1f" % (form, t(lambda: ops.conv_s2_block_wreg(x, 0, cin, f3, sc, sh, f1, sc, sh, cout, G, form=form)))
     print(line)
