@@ -467,10 +467,14 @@ int w2c_upsample32_argmax(const float* low, int M, int h, int w, int low_cstride
  * (when labels == NULL) the label map are written; the evaluator reads n*n int64 counters per validation pass.
  * gt   : ground-truth labels [M, 32h, 32w], u8 (gt_is_i64=0; 4-byte aligned) or int64 (gt_is_i64=1) as the loader
  *        yields them; values outside [0, n) are ignored (the reference's mask)
- * hist : int64 [n*n], ACCUMULATED into (zero it once per evaluation); n_classes <= 64.  Exact (integer atomics). */
+ * hist : int64 [n*n], ACCUMULATED into (zero it once per evaluation); n_classes <= 64.  Exact (integer atomics).
+ * ws   : optional (NULL / ws_partials 0: every workgroup adds its counts to hist directly -- ~1e5 atomics on n*n addresses) workspace of
+ *        the two-level flush: int64 [ws_partials * S + 16], ws_partials = 32, S = n*n rounded up to 16, zeroed by the caller ONCE and left zeroed by every
+ *        launch (the last workgroup to finish moves the partial sums into hist).  One workspace per stream: launches that share one
+ *        must be stream-ordered.  Same result either way. */
 int w2c_upsample32_argmax_confusion(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                                     const void* gt, int gt_is_i64, uint8_t* labels, long long* hist,
-                                    w2c_stream_t stream);
+                                    long long* ws, int ws_partials, w2c_stream_t stream);
 /* The same histogram for label maps that already exist: pred u8 [n_pixels], gt u8 or int64 [n_pixels]. */
 int w2c_confusion_matrix(const void* gt, int gt_is_i64, const uint8_t* pred, long long n_pixels, int n_classes,
                          long long* hist, w2c_stream_t stream);

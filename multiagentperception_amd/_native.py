@@ -84,7 +84,7 @@ SIGNATURES = {
     "w2c_cross_entropy2d_workspace_bytes": [_ll],
     "w2c_cross_entropy2d_forward": [_vp, _vp, _vp, _i, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp],
     "w2c_cross_entropy2d_backward": [_vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp],
-    "w2c_upsample32_argmax_confusion": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "w2c_upsample32_argmax_confusion": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "w2c_confusion_matrix": [_vp, _i, _vp, _ll, _i, _vp, _vp],
     "w2c_nchw_f32_to_nhwc_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_nhwc_bf16_to_nchw_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],

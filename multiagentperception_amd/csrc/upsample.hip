@@ -93,13 +93,17 @@ __global__ __launch_bounds__(256) void upsample32_kernel(const float* __restrict
 // lanes all hit one bin, the common case inside a segment, adds 64 with one atomic) and flushes its non-zero bins
 // with one 64-bit global atomic each.  Integer atomics: the result is exact and order-independent.
 constexpr int ARG_ROWS = 8;
+constexpr int CONF_WS_PARTIALS = 32;                // partial histograms of the confusion kernel's two-level flush (include/w2c_hip.h)
 constexpr int ARG_MAXC = 12;                        // classes handled by the register form (3 x 16 B per corner)
 // MULTI: more than ARG_MAXC classes -- the classes are walked in chunks of ARG_MAXC with the rows' running (best, index) kept across
 // chunks (64 more registers); the comparison order is still class-ascending, so ties keep the lowest index.
+// Occupancy matters more than anything else here: cfg 2 is 640 workgroups, i.e. 2.5 per CU -- at 3 waves per SIMD (<= 168 VGPRs) they
+// are all resident at once, at 2 (the confusion form took 172) the launch runs two rounds and takes twice the labels-only time.
 template <bool CONF, bool GT64, bool MULTI = false>
-__global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MULTI ? 1 : 3, 8))) void upsample32_argmax_kernel(const float* __restrict__ low, int h, int w, int lcs, int ncls,
                                                                 uint8_t* labels_arg, const void* gt_arg,
-                                                                unsigned long long* hist_arg) {
+                                                                unsigned long long* hist_arg, unsigned long long* ws, int ws_k,
+                                                                int ws_stride) {
     uint8_t* const __restrict__ labels = w2c_resolve(labels_arg);   // indirect operands (caller-owned tensors of a captured forward)
     const void* const __restrict__ gt = w2c_resolve(gt_arg);
     unsigned long long* const __restrict__ hist = w2c_resolve(hist_arg);
@@ -144,20 +148,47 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
         uint8_t* obase = labels ? labels + ((size_t)m * H + (size_t)band * ARG_ROWS) * W + gx * 4 : nullptr;
         // CONF: the ground-truth labels of the thread's 8 x 4 pixels, all loads in flight with the corner vectors (read one row at a
         // time next to their use they were 8 dependent round trips per thread: +16 us on the 12 us argmax)
-        uint32_t gt8[CONF && !GT64 ? ARG_ROWS : 1];
-        long long gt64[CONF && GT64 ? ARG_ROWS : 1][4];
+        uint32_t gt8[CONF ? ARG_ROWS : 1];
         if (CONF) {
+            if (GT64) {
+                // int64 labels (the loader's dtype): narrowed to a byte per pixel as they arrive (0xFF = outside [0, n)), four rows'
+                // loads in flight at a time -- all eight at once are 64 registers the kernel does not have (see the occupancy note)
 #pragma unroll
-            for (int ry = 0; ry < ARG_ROWS; ++ry) {
-                const size_t pix = ((size_t)m * H + band * ARG_ROWS + ry) * W + gx * 4;
-                if (GT64) {
-                    const long long* gp = reinterpret_cast<const long long*>(gt) + pix;
+                for (int half = 0; half < 2; ++half) {
+                    long long g64[ARG_ROWS / 2][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) gt64[GT64 ? ry : 0][e] = gp[e];
-                } else {
-                    gt8[GT64 ? 0 : ry] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(gt) + pix);
+                    for (int r = 0; r < ARG_ROWS / 2; ++r) {
+                        const size_t pix = ((size_t)m * H + band * ARG_ROWS + half * (ARG_ROWS / 2) + r) * W + gx * 4;
+                        const long long* gp = reinterpret_cast<const long long*>(gt) + pix;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g64[r][e] = gp[e];
+                    }
+#pragma unroll
+                    for (int r = 0; r < ARG_ROWS / 2; ++r) {
+                        uint32_t pk = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            pk |= ((g64[r][e] >= 0 && g64[r][e] < ncls) ? (uint32_t)g64[r][e] : 0xFFu) << (8 * e);
+                        gt8[half * (ARG_ROWS / 2) + r] = pk;
+                    }
+                    // (the later loads must not be hoisted above this point again: neither by the IR passes nor by the scheduler)
+                    asm volatile("" : "+v"(gt8[half * 4]), "+v"(gt8[half * 4 + 1]), "+v"(gt8[half * 4 + 2]), "+v"(gt8[half * 4 + 3])::"memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int ry = 0; ry < ARG_ROWS; ++ry) {
+                    const size_t pix = ((size_t)m * H + band * ARG_ROWS + ry) * W + gx * 4;
+                    gt8[ry] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(gt) + pix);
                 }
             }
+        }
+        // CONF: the 32 bins of the thread's pixels, packed (bins < 144 in a byte when ncls <= 12, else < 4096 in 16 bits)
+        constexpr unsigned NOBIN = MULTI ? 0xFFFFu : 0xFFu;
+        unsigned binp[CONF ? (MULTI ? 2 * ARG_ROWS : ARG_ROWS) : 1];
+        if (CONF) {
+#pragma unroll
+            for (int i = 0; i < (MULTI ? 2 * ARG_ROWS : ARG_ROWS); ++i) binp[i] = 0;
         }
         for (int cbase = 0; cbase < (MULTI ? ncls : 1); cbase += ARG_MAXC) {
         // the four corners' class vectors (lcs >= 4 ceil(ncls / 4) floats, 16-byte aligned rows: checked by the launcher)
@@ -215,46 +246,90 @@ __global__ __launch_bounds__(256) void upsample32_argmax_kernel(const float* __r
             const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
             if (labels) *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W) = packed;
             if (CONF) {
-                int bin[4];
+                // this row's four bins n * gt + pred (NOBIN: gt outside [0, n)), kept for the histogram step behind the rows
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const long long g = GT64 ? gt64[GT64 ? ry : 0][e] : (long long)((gt8[GT64 ? 0 : ry] >> (8 * e)) & 0xFF);
-                    bin[e] = (g >= 0 && g < ncls) ? (int)g * ncls + bi[e] : -1;
-                }
-                const int lane = (int)(threadIdx.x & 63);
-                // the common case inside a segment: every pixel of the wave's row (64 lanes x 4 columns) falls in ONE bin -> one atomic
-                const int lead = __builtin_amdgcn_readfirstlane(bin[0]);
-                const int diff = (bin[0] ^ lead) | (bin[1] ^ lead) | (bin[2] ^ lead) | (bin[3] ^ lead);
-                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-                if (lead >= 0 && __builtin_amdgcn_ballot_w64(diff == 0) == active) {
-                    if (lane == __builtin_ctzll(active)) atomicAdd(&lh[lead], 4u * (unsigned)__builtin_popcountll(active));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // one LDS atomic per bin for the wave's two most frequent-first bins (segment borders: usually that is all),
-                        // per-lane atomics for the rest.  (Peeling EVERY distinct bin off with ballots is slower on noise-like labels --
-                        // the synthetic benchmark's -- than the conflicting atomics it avoids: 1.328 vs 1.275 ms per evaluator step.)
-                        const bool ok = bin[e] >= 0;
-                        unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);          // lanes that still have to be counted
-#pragma unroll
-                        for (int it = 0; it < 2 && todo; ++it) {                            // wave-uniform: the two most likely bins
-                            const int leader = __builtin_ctzll(todo);
-                            const int b0 = __builtin_amdgcn_readlane(bin[e], leader);
-                            const unsigned long long same = __builtin_amdgcn_ballot_w64(ok && bin[e] == b0) & todo;
-                            if (lane == leader) atomicAdd(&lh[b0], (unsigned)__builtin_popcountll(same));
-                            todo &= ~same;
-                        }
-                        if ((todo >> lane) & 1ull) atomicAdd(&lh[bin[e]], 1u);              // whatever is left (noise-like labels): per lane
-                    }
+                    const int g = (int)((gt8[CONF ? ry : 0] >> (8 * e)) & 0xFF);        // (u8 labels: 255 >= n is outside too: n <= 64)
+                    const unsigned b = g < ncls ? (unsigned)(g * ncls + bi[e]) : NOBIN;
+                    if (MULTI) binp[MULTI ? 2 * ry + (e >> 1) : 0] |= b << (16 * (e & 1));
+                    else binp[MULTI ? 0 : ry] |= b << (8 * e);
                 }
             }
         }
         }   // class chunks
+        if (CONF) {
+            // Histogram step, once per thread (the first form did this per ROW with wave-wide ballots: 8 x the scalar traffic, and its
+            // unrolled slow paths made the kernel 2.2x the labels-only one).  An upsampled x32 prediction is constant over almost every
+            // 8 x 4 block and real label maps are piecewise constant: a thread whose 32 pixels share ONE bin adds 32 with one LDS atomic,
+            // a wave whose 64 threads all do (the common case inside a segment) adds 2048 with one; only threads on a border (or
+            // noise-like labels: the synthetic benchmark's) count their pixels one by one.
+            constexpr int NP = MULTI ? 2 * ARG_ROWS : ARG_ROWS;
+            const unsigned first = binp[0] & NOBIN;
+            const unsigned rep = MULTI ? first * 0x00010001u : first * 0x01010101u;
+            unsigned diff = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) diff |= binp[i] ^ rep;
+            const bool uni = diff == 0;
+            const int lane = (int)(threadIdx.x & 63);
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+            const unsigned lead = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+            if (__builtin_amdgcn_ballot_w64(uni && first == lead) == active) {
+                if (lead != NOBIN && lane == __builtin_ctzll(active))
+                    atomicAdd(&lh[lead], (unsigned)(4 * ARG_ROWS) * (unsigned)__builtin_popcountll(active));
+            } else if (uni) {
+                if (first != NOBIN) atomicAdd(&lh[first], (unsigned)(4 * ARG_ROWS));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int e = 0; e < (MULTI ? 2 : 4); ++e) {
+                        const unsigned b = (binp[i] >> ((MULTI ? 16 : 8) * e)) & NOBIN;
+                        if (b != NOBIN) atomicAdd(&lh[b], 1u);
+                    }
+            }
+        }
     }
     if (CONF) {
         __syncthreads();
-        for (int i = threadIdx.x; i < ncls * ncls; i += 256)
-            if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+        const int nbins = ncls * ncls;
+        if (ws) {
+            // two-level flush: 640 workgroups x up to 121 64-bit atomics on the caller's 121 counters (8 cache lines) cost 5-9 us of the
+            // launch; here the workgroups spread over ws_k partial histograms (a line-aligned stride apart), and the LAST workgroup to
+            // finish (a counter behind the partials) moves their sums into hist and leaves the workspace zeroed for the next launch.
+            // Integer sums: exact and order-independent, as before.
+            __shared__ int is_last;
+            const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+            unsigned long long* part = ws + (size_t)(wg % (unsigned)ws_k) * ws_stride;
+            // no __threadfence() here: on this part an agent-scope fence writes the XCD's L2 back (every workgroup paying for the dirty
+            // lines of the kernels before it: +28 us).  Device-scope atomics are performed at the coherence point; a thread that has
+            // its atomics' RETURN values knows they have been, and the barrier then orders them before the counter's increment.
+            unsigned long long seen = 0;
+            for (int i = threadIdx.x; i < nbins; i += 256)
+                if (lh[i]) seen += atomicAdd(&part[i], (unsigned long long)lh[i]);
+            asm volatile("" ::"v"((unsigned)seen));
+            __syncthreads();
+            unsigned long long* counter = ws + (size_t)ws_k * ws_stride;
+            if (threadIdx.x == 0) is_last = atomicAdd(counter, 1ull) == (unsigned long long)(gridDim.x * gridDim.y) - 1ull;
+            __syncthreads();
+            if (is_last) {
+                // thread = (bin, half of the partials): its 16 read-and-zero atomics are independent and all in flight together
+                // (a rolled loop of returning atomics is one L2 round trip EACH: 32 of them cost 37 us)
+                for (int i = threadIdx.x & 127; i < nbins; i += 128) {
+                    const int k0 = (threadIdx.x >> 7) * (CONF_WS_PARTIALS / 2);
+                    unsigned long long v[CONF_WS_PARTIALS / 2];
+#pragma unroll
+                    for (int k = 0; k < CONF_WS_PARTIALS / 2; ++k) v[k] = atomicExch(&ws[(size_t)(k0 + k) * ws_stride + i], 0ull);
+                    unsigned long long sum = 0;
+#pragma unroll
+                    for (int k = 0; k < CONF_WS_PARTIALS / 2; ++k) sum += v[k];
+                    if (sum) atomicAdd(&hist[i], sum);
+                }
+                if (threadIdx.x == 0) atomicExch(counter, 0ull);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nbins; i += 256)
+                if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+        }
     }
 }
 
@@ -401,16 +476,16 @@ extern "C" int w2c_upsample32_argmax(const float* low, int M, int h, int w, int 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n_classes <= ARG_MAXC)
         hipLaunchKernelGGL((upsample32_argmax_kernel<false, false, false>), argmax_grid(M, h, w), dim3(256), 0, s, low, h, w, low_cstride,
-                           n_classes, labels, nullptr, nullptr);
+                           n_classes, labels, nullptr, nullptr, nullptr, 0, 0);
     else
         hipLaunchKernelGGL((upsample32_argmax_kernel<false, false, true>), argmax_grid(M, h, w), dim3(256), 0, s, low, h, w, low_cstride,
-                           n_classes, labels, nullptr, nullptr);
+                           n_classes, labels, nullptr, nullptr, nullptr, 0, 0);
     return w2c_launch_status();
 }
 
 extern "C" int w2c_upsample32_argmax_confusion(const float* low, int M, int h, int w, int low_cstride, int n_classes,
                                                const void* gt, int gt_is_i64, uint8_t* labels, long long* hist,
-                                               w2c_stream_t stream) {
+                                               long long* ws, int ws_partials, w2c_stream_t stream) {
     w2c_clear_error();
     if (!low || !gt || !hist || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || n_classes > 64 || low_cstride < n_classes)
         return W2C_E_ARG;
@@ -423,13 +498,19 @@ extern "C" int w2c_upsample32_argmax_confusion(const float* low, int M, int h, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned long long* hp = reinterpret_cast<unsigned long long*>(hist);
     const dim3 grid = argmax_grid(M, h, w, true);
+    // optional workspace of the two-level flush: ws_partials histograms, w2c_confusion_ws_stride(n_classes) counters apart, + 16 counters
+    // behind them; zeroed by the caller ONCE, left zeroed by every launch; one workspace per stream (launches sharing one must be ordered)
+    const int ws_stride = (n_classes * n_classes + 15) / 16 * 16;
+    if (ws && ws_partials != 0 && ws_partials != CONF_WS_PARTIALS) return W2C_E_ARG;
+    unsigned long long* wsp = (ws && ws_partials > 0) ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
+    if (wsp && (reinterpret_cast<uintptr_t>(ws) & 7)) return W2C_E_ARG;
     const bool multi = n_classes > ARG_MAXC;
     if (gt_is_i64) {
-        if (multi) hipLaunchKernelGGL((upsample32_argmax_kernel<true, true, true>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
-        else hipLaunchKernelGGL((upsample32_argmax_kernel<true, true, false>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
+        if (multi) hipLaunchKernelGGL((upsample32_argmax_kernel<true, true, true>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp, wsp, ws_partials, ws_stride);
+        else hipLaunchKernelGGL((upsample32_argmax_kernel<true, true, false>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp, wsp, ws_partials, ws_stride);
     } else {
-        if (multi) hipLaunchKernelGGL((upsample32_argmax_kernel<true, false, true>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
-        else hipLaunchKernelGGL((upsample32_argmax_kernel<true, false, false>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp);
+        if (multi) hipLaunchKernelGGL((upsample32_argmax_kernel<true, false, true>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp, wsp, ws_partials, ws_stride);
+        else hipLaunchKernelGGL((upsample32_argmax_kernel<true, false, false>), grid, dim3(256), lds, s, low, h, w, low_cstride, n_classes, labels, gt, hp, wsp, ws_partials, ws_stride);
     }
     return w2c_launch_status();
 }

@@ -692,6 +692,14 @@ class CommEngine:
         low, prob, action, nnz = self.graph_and_low(u_all, keys_all, querys_local, B, N, q_lo, q_n, mode)
         return ops.upsample_bilinear32(low, self.n_classes), prob, action, nnz, low
 
+    def _confusion_ws(self, dev):
+        """this engine's workspace of the confusion kernel's two-level flush (first created by an eager / warm-up call, never inside a
+        capture; engines in flight on different streams each have their own)"""
+        ws = self.__dict__.get("_conf_ws")
+        if ws is None:
+            ws = self._conf_ws = ops.confusion_workspace(dev, self.n_classes)
+        return ws
+
     # ---- whole single-GPU forward, optionally replayed from a captured HIP graph ------------------
     def forward_local(self, x, B, N, mode, use_graph=False, labels=False, confusion=None):
         """-> pred f32 [N*B,n_cls,H,W] (fresh tensor; or u8 class labels [N*B,H,W] when labels=True: the
@@ -701,7 +709,7 @@ class CommEngine:
         else None."""
         if confusion is not None:
             finish = lambda low: ops.upsample32_argmax_confusion(low, self.n_classes, confusion[0], confusion[1],  # noqa: E731
-                                                                 want_labels=labels)
+                                                                 want_labels=labels, ws=self._confusion_ws(low.device))
         elif labels:
             finish = lambda low: ops.upsample32_argmax(low, self.n_classes)             # noqa: E731
         else:
@@ -772,7 +780,8 @@ class CommEngine:
             low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode, pack2=pack2)
             pack = self._last_pack
             if confusion is not None:
-                ops.upsample32_argmax_confusion(low, self.n_classes, gts, hists, want_labels=labels, out=outs)
+                ops.upsample32_argmax_confusion(low, self.n_classes, gts, hists, want_labels=labels, out=outs,
+                                                ws=self._confusion_ws(low.device))
             elif labels:
                 ops.upsample32_argmax(low, self.n_classes, out=outs)
             else:

@@ -1191,20 +1191,34 @@ def _gt_kind(gt):
     raise W2CError("ground-truth labels must be uint8 or int64, got %s" % gt.dtype)
 
 
-def upsample32_argmax_confusion(low, n_classes, gt, hist, want_labels=False, out=None):
+CONFUSION_WS_PARTIALS = 32
+
+
+def confusion_workspace(dev, n_classes):
+    """zeroed int64 workspace of w2c_upsample32_argmax_confusion's two-level flush (include/w2c_hip.h); the kernel leaves it zeroed.
+    One per stream: the engines keep their own."""
+    stride = (n_classes * n_classes + 15) // 16 * 16
+    return torch.zeros(CONFUSION_WS_PARTIALS * stride + 16, dtype=torch.int64, device=dev)
+
+
+def upsample32_argmax_confusion(low, n_classes, gt, hist, want_labels=False, out=None, ws=None):
     """K9 + class argmax + confusion matrix (metrics.py:99-108) in one launch.  gt: u8 or i64 [M,32h,32w];
-    hist: int64 [n*n] accumulated in place.  Returns the u8 label map when want_labels, else None.  (gt / hist / out may be SlotRefs.)"""
+    hist: int64 [n*n] accumulated in place.  Returns the u8 label map when want_labels, else None.  (gt / hist / out may be SlotRefs.)
+    ws: confusion_workspace() of the calling stream, or None (direct flush)."""
     dev = _need_gpu(low, gt, hist)
     M, h, w, lcs = low.shape
     if tuple(gt.shape) != (M, 32 * h, 32 * w):
         raise W2CError("confusion: labels %s do not match the %s prediction map" % (tuple(gt.shape), (M, 32 * h, 32 * w)))
     if hist.dtype != torch.int64 or hist.numel() != n_classes * n_classes:
         raise W2CError("confusion: hist must be int64 [%d]" % (n_classes * n_classes))
+    if ws is not None and (ws.dtype != torch.int64 or ws.numel() < CONFUSION_WS_PARTIALS * ((n_classes * n_classes + 15) // 16 * 16) + 16):
+        raise W2CError("confusion: workspace too small (ops.confusion_workspace)")
     if out is None:
         out = torch.empty((M, 32 * h, 32 * w), dtype=torch.uint8, device=dev) if want_labels else None
     with torch.cuda.device(dev):
         check(_native.lib().w2c_upsample32_argmax_confusion(_p(low), M, h, w, lcs, n_classes, _p(gt), _gt_kind(gt), _p(out),
-                                                            _p(hist), _stream(dev)), "w2c_upsample32_argmax_confusion")
+                                                            _p(hist), _p(ws), CONFUSION_WS_PARTIALS if ws is not None else 0,
+                                                            _stream(dev)), "w2c_upsample32_argmax_confusion")
     return out
 
 

@@ -826,6 +826,34 @@ def test_upsample32_argmax_confusion_equals_separate_steps():
         keep = gt < 11
         want = np.bincount((11 * gt[keep] + lab.cpu()[keep].long()).numpy(), minlength=121)
         np.testing.assert_array_equal(hist.cpu().numpy(), 2 * want)
+        # the two-level flush through a workspace: same counters, workspace left zeroed (so the next launch can reuse it)
+        ws = ops.confusion_workspace(_dev(), 11)
+        for _ in range(3):
+            ops.upsample32_argmax_confusion(low, 11, gt.to(dt).to(_dev()), hist, ws=ws)
+        np.testing.assert_array_equal(hist.cpu().numpy(), 5 * want)
+        assert not bool(ws.any())
+
+
+@pytest.mark.parametrize("ncls", [11, 19, 40])
+def test_confusion_on_piecewise_constant_labels_and_many_classes(ncls):
+    """segment-like ground truth (the thread / wave fast paths: one bin per 8 x 4 block / per wave) with borders cutting through
+    blocks, ignored labels, and class counts on both sides of the 12-class register form (16-bit packed bins above it)"""
+    from multiagentperception_amd import ops
+    gen = torch.Generator().manual_seed(100 + ncls)
+    M, h, w = 4, 8, 8
+    lcs = (ncls + 3) // 4 * 4
+    low = torch.randn(M, h, w, lcs, generator=gen).to(_dev())
+    yy, xx = torch.meshgrid(torch.arange(32 * h), torch.arange(32 * w), indexing="ij")
+    gt = torch.stack([((yy + 7 * m) // 37 + (xx // (53 + m))) % (ncls + 1) for m in range(M)])     # value ncls = ignored
+    gt[0, 100:130, 3:200] = torch.randint(0, ncls, (30, 197), generator=gen)                       # a noisy patch
+    lab = ops.upsample32_argmax(low, ncls)
+    keep = gt < ncls
+    want = np.bincount((ncls * gt[keep] + lab.cpu()[keep].long()).numpy(), minlength=ncls * ncls)
+    for dt in (torch.uint8, torch.int64):
+        for ws in (None, ops.confusion_workspace(_dev(), ncls)):
+            hist = torch.zeros(ncls * ncls, dtype=torch.int64, device=_dev())
+            ops.upsample32_argmax_confusion(low, ncls, gt.to(dt).to(_dev()), hist, ws=ws)
+            np.testing.assert_array_equal(hist.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("cin,cout,hw,M,G", [(64, 128, 64, 5, 2), (128, 256, 32, 20, 2), (256, 512, 16, 20, 2), (256, 512, 32, 3, 1),

@@ -42,4 +42,7 @@ timed("upsample_bilinear32 (f32 logits, 231 MB)", lambda: ops.upsample_bilinear3
 timed("upsample32_argmax (u8 labels, 5 MB)", lambda: ops.upsample32_argmax(low, n, out=lab), lab.numel())
 timed("  + confusion, u8 noise labels", lambda: ops.upsample32_argmax_confusion(low, n, gt8, hist), lab.numel())
 timed("  + confusion, u8 segment labels", lambda: ops.upsample32_argmax_confusion(low, n, seg, hist), lab.numel())
+ws = ops.confusion_workspace(low.device, n)
+timed("  + confusion, u8 noise labels, two-level flush", lambda: ops.upsample32_argmax_confusion(low, n, gt8, hist, ws=ws), lab.numel())
+timed("  + confusion, u8 segment labels, two-level flush", lambda: ops.upsample32_argmax_confusion(low, n, seg, hist, ws=ws), lab.numel())
 timed("  + confusion, i64 segment labels", lambda: ops.upsample32_argmax_confusion(low, n, seg.long(), hist), lab.numel())
