@@ -25,8 +25,11 @@
 //     before the exchange) + ReLU, bf16 pack, v_permlane32_swap pairs the half-waves' channel quads into 16-byte stores.
 // LDS: 72 KB of patch buffers -> two workgroups per CU; 128 AGPRs + <= 128 VGPRs -> two waves per SIMD.
 // The K order differs from the ring kernels' (partial sums per K group): results agree to f32 rounding, not bit for bit.
-template <int NN, int KS, int ABL = 0, int DW = 8>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
-__global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs p) {
+// NB = 32-channel blocks per wave (2: the wave tile above; 1: 128 pixels x 32 channels -- twice the waves on the same workgroup tiles for
+// launches that cannot fill the chip's wave slots (M <= 20 tail convs, a rank's share of a sharded batch): one wave per SIMD hides none of
+// its weight-load and LDS latencies.  Same K groups, same reduction order: bit-identical to NB = 2.
+template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
+__global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PW = 18, NP = 180, NPIECE = 23;  // patch: 10 x 18 pixels, 128 B each, DMA'd in 1 KB pieces of 8 pixels
     constexpr int NW = NN * KS;
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     // of matrix pipe per wave: with one slice per step (KS = 4) two steps ahead is only ~0.5-1k cycles -- less than an L2 round
     // trip under load -- so that form runs a 9-deep ring (72 VGPRs), DW steps ahead
     constexpr int R = (KK == 1 && DW > 2) ? 9 : 3, D = KK == 1 ? DW : 2;
-    constexpr int NB_SYNC = 16 * KK > 56 ? 56 : 16 * KK;   // weight loads a wave issues between a patch and the chunk sync that needs it (>=)
+    constexpr int CW = 32 * NB;                    // channels per wave
+    constexpr int NB_SYNC = 8 * NB * KK > 56 ? 56 : 8 * NB * KK;   // weight loads a wave issues between a patch and the chunk sync that needs it (>=)
     static_assert(KS == 1 || KS == 2 || KS == 4, "K split");
     // one dummy "a" operand makes the backend pick the AGPR form of every builtin MFMA here (accumulators in AGPRs)
     asm volatile("" ::"a"(0));
@@ -70,14 +74,17 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     }
     const int txi = tsp % tiles_x, tyi = (tsp / tiles_x) % tiles_y, img = tsp / (tiles_x * tiles_y);
     const int y0 = tyi * 8, x0 = txi * 16;
-    const int n0 = tn * (NN * 64) + nw * 64;        // this wave's first output channel inside the group
+    const int n0 = tn * (NN * CW) + nw * CW;        // this wave's first output channel inside the group
     const int nchunks = p.Cin >> 6, KT = nchunks * 9;
 
     // BN scale | shift of this wave's 64 channels: parked in LDS (512 B per wave behind the patch / exchange area) for the epilogue
-    constexpr int SS_BASE = (3 * PATCH_STRIDE > NW * 16384 ? 3 * PATCH_STRIDE : NW * 16384);
+    constexpr int XR = 8192 * NB;                  // exchange region of a wave (round 1: two pixel blocks x NB accumulators x 4 KB)
+    constexpr int SS_BASE = (3 * PATCH_STRIDE > NW * XR ? 3 * PATCH_STRIDE : NW * XR);
     float* const ssw = reinterpret_cast<float*>(smem + SS_BASE + wave * 512) + lhi * 4;
-    reinterpret_cast<float*>(smem + SS_BASE + wave * 512)[lane] = p.scale[g * p.Cout + n0 + lane];
-    reinterpret_cast<float*>(smem + SS_BASE + wave * 512)[64 + lane] = p.shift[g * p.Cout + n0 + lane];
+    if (NB == 2 || lane < CW) {
+        reinterpret_cast<float*>(smem + SS_BASE + wave * 512)[lane] = p.scale[g * p.Cout + n0 + lane];
+        reinterpret_cast<float*>(smem + SS_BASE + wave * 512)[64 + lane] = p.shift[g * p.Cout + n0 + lane];
+    }
 
     // ---- input patch: LDS-DMA from inline asm (hidden from the compiler's vmcnt bookkeeping: counted by hand below) ----
     const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)W2C_LPTR(smem));
@@ -113,19 +120,20 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     const int wv = lane * 16 + kg * KK * 1024;      // this lane's 16 bytes of this wave's first k slice inside a (32 channels, K-step) block
     const int nb0 = n0 >> 5;
     const int ws0 = nb0 * KT * 4096, ws1 = ws0 + KT * 4096;
-    auto load_a = [&](u32x4_t (&A)[2][KK], int t) {
+    auto load_a = [&](u32x4_t (&A)[NB][KK], int t) {
 #pragma unroll
         for (int q = 0; q < KK; ++q) {
             A[0][q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv + q * 1024, ws0 + t * 4096, 0));
-            A[1][q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv + q * 1024, ws1 + t * 4096, 0));
+            if constexpr (NB == 2)
+                A[NB - 1][q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv + q * 1024, ws1 + t * 4096, 0));
         }
     };
 
-    f32x16_t acc[4][2];
+    f32x16_t acc[4][NB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -164,23 +172,23 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const bf16x8_t*>(r + blkoff[i]);
     };
-    auto mfma8 = [&](const u32x4_t (&A)[2][KK], const bf16x8_t (&fb)[4], int q) {
+    auto mfma8 = [&](const u32x4_t (&A)[NB][KK], const bf16x8_t (&fb)[4], int q) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NB; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[j][q]), fb[i], acc[i][j], 0, 0, 0);
     };
 
     // ---- main loop.  VMEM queue of a wave, in issue order:  P(0) P(1) A(0) A(1) | A(2) .. A(9) [sync 0] P(2) A(10) | ...
     // chunk sync cc (before the last tap of chunk cc) waits until at most the weight loads issued after P(cc+1) are outstanding. ----
-    u32x4_t AR[R][2][KK];
+    u32x4_t AR[R][NB][KK];
     bf16x8_t fb[2][4];
     issue_patch(0, 0);
     if (nchunks > 1) issue_patch(1, 1);
 #pragma unroll
     for (int d = 0; d < D; ++d) load_a(AR[d], d);
-    if (nchunks > 1) wait_vmcnt<P_INSTR + 2 * KK * D>(); else wait_vmcnt<2 * KK * D>();
+    if (nchunks > 1) wait_vmcnt<P_INSTR + NB * KK * D>(); else wait_vmcnt<NB * KK * D>();
     pipeline_barrier();
     dbg_stamp(p, 1);
     read_b(fb[0], smem, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 1)) {
                 load_a(AR[(tap + D) % R], t0 + tap + D);   // past the last K-step: other rows or zeros, never used
-                __builtin_amdgcn_sched_group_barrier(0x020, 2 * KK, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, NB * KK, 0);
             }
             auto slice = [&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
 #pragma unroll
                     for (int z = 0; z < 4; ++z) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
                     }
                 }
             };
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     // ---- epilogue operands, issued before the exchange so that their latency hides under it: this wave will own pixel blocks
     // acc[0 .. 4 / KS) (see the reduction below); residual in the STORE layout (16 bytes = 8 consecutive channels per lane) ----
     constexpr int CNT = 4 / KS;
-    uint4 rres[CNT][2][2];
+    uint4 rres[CNT][NB][2];
     unsigned eoff[CNT];                            // element offsets (the tensors are < 2 GiB: fill_args / ops.conv_igemm)
 #pragma unroll
     for (int ii = 0; ii < CNT; ++ii) {
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
         eoff[ii] = (unsigned)((((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.ygs + n0 + lhi * 8);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -278,10 +286,10 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
 #pragma unroll
         for (int i = 0; i < CNTD; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NB; ++j) {
 #pragma unroll
                 for (int eg = 0; eg < 4; ++eg)
-                    *reinterpret_cast<f32x4_t*>(dst + ((i * 2 + j) * 4 + eg) * 1024 + lane * 16) =
+                    *reinterpret_cast<f32x4_t*>(dst + ((i * NB + j) * 4 + eg) * 1024 + lane * 16) =
                         f32x4_t{acc[I0 + i][j][eg * 4], acc[I0 + i][j][eg * 4 + 1], acc[I0 + i][j][eg * 4 + 2], acc[I0 + i][j][eg * 4 + 3]};
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -291,10 +299,10 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
 #pragma unroll
         for (int i = 0; i < CNTD; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NB; ++j) {
 #pragma unroll
                 for (int eg = 0; eg < 4; ++eg) {
-                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + ((i * 2 + j) * 4 + eg) * 1024 + lane * 16);
+                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + ((i * NB + j) * 4 + eg) * 1024 + lane * 16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[I0 + i][j][eg * 4 + e] += v[e];
                 }
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     // ---- output: pixel blocks [I0, I0 + CNT) x this wave's 64 channels, register-direct ----
     auto finalize = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const f32x4_t sc0 = *reinterpret_cast<const f32x4_t*>(ssw + j * 32 + m * 16);
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
     };
     using I0_ = std::integral_constant<int, 0>; using I1_ = std::integral_constant<int, 1>;
     using I2_ = std::integral_constant<int, 2>;
-    auto xr = [&](int kgx) { return smem + (kgx * NN + nw) * 16384; };        // exchange region of wave (nw, kgx)
+    auto xr = [&](int kgx) { return smem + (kgx * NN + nw) * XR; };           // exchange region of wave (nw, kgx)
     if constexpr (KS >= 2) {
         dump(I2_{}, I2_{}, xr(kg));                                            // round 1 with K group kg ^ 1
         pipeline_barrier();
@@ -358,27 +366,27 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs 
 #endif
 }
 
-template <int NN, int KS, int ABL = 0, int DW = 8>
+template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2>
 int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % (NN * 64) != 0 || a.H % 8 != 0 || a.W % 16 != 0 || a.y_f32 || a.y8 ||
+    if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % (NN * 32 * NB) != 0 || a.H % 8 != 0 || a.W % 16 != 0 || a.y_f32 || a.y8 ||
         !a.y || a.ws)
         return W2C_E_ARG;
     a.ntm = a.M * (a.H / 8) * (a.W / 16);
-    a.ntn = a.Cout / (NN * 64);
+    a.ntn = a.Cout / (NN * 32 * NB);
     constexpr int patch = 3 * ((23 + NN * KS - 1) / (NN * KS)) * NN * KS * 1024;
-    constexpr int xchg = KS > 1 ? NN * KS * 16384 : 0;
+    constexpr int xchg = KS > 1 ? NN * KS * 8192 * NB : 0;
     constexpr int lds = (patch > xchg ? patch : xchg) + NN * KS * 512;
     static_assert(lds <= 160 * 1024, "LDS");
     static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);
     const long wbytes = (long)a.Cout * 9 * a.Cin * 2;
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20))) && !(a.ntm & 1) && !(a.ntn & 3);
-    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW, NB>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
     return w2c_launch_status();
 }

@@ -1084,6 +1084,9 @@ WREG_CASES = [
     (0, 2, 16, 16, 256, 128, 1, True, True, 0, 0),         # the library's own choice of form
     (93, 2, 16, 32, 512, 256, 1, True, True, 0, 0),        # weight-heavy: XCD-aware tile placement (4 channel tiles, 8 pixel tiles)
     (94, 1, 8, 32, 128, 64, 1, False, True, 0, 0),
+    (95, 2, 16, 32, 256, 128, 2, True, True, 8, 8),        # 32 channels per wave: 8 waves per workgroup
+    (96, 3, 8, 16, 512, 64, 1, True, False, 0, 0),
+    (96, 1, 16, 16, 192, 192, 1, False, True, 0, 0),       # odd chunk count, 3 channel tiles
 ]
 
 
@@ -1234,6 +1237,21 @@ def test_s2_block_front_wreg_is_independent_of_image_count_and_groups_and_repeat
         for _ in range(40):
             t2, i2 = ops.conv_s2_block_wreg(x, 0, cin, f3, sc3, sh3, f1, sc1, sh1, cout, 2, form=form)
             assert torch.equal(t2, t) and torch.equal(i2, idt)
+
+
+def test_conv3x3_wreg_32_channel_wave_forms_are_bit_identical_to_the_64_channel_ones():
+    """forms 95 / 96 put twice the waves on the same workgroup tile (32 channels per wave) for launches too small to fill the chip's
+    wave slots; same K groups and reduction order, so the choice (which depends on the launch size) never shows in the bits"""
+    from multiagentperception_amd import ops
+    for cin, cout, H, W, M in ((512, 512, 16, 16, 5), (256, 256, 32, 32, 2), (512, 256, 16, 16, 3)):
+        case = (93, M, H, W, cin, cout, 1, True, True, 0, 0)
+        xs, ws, scale, shift, ress, x_dev, w_dev, res_dev = _wreg_setup(case, 5 + cin + cout)
+        wfrag = ops.pack_wfrag_device(w_dev, cin)
+        sc, sh = scale.to(_dev()), shift.to(_dev())
+        ref = ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, residual=res_dev, form=93).clone()
+        for form in (94, 95, 96, 0):
+            for _ in range(10):
+                assert torch.equal(ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, residual=res_dev, form=form), ref), form
 
 
 def test_conv3x3_wreg_xcd_placement_leaves_results_bit_identical(lib_option):

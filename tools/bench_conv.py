@@ -35,13 +35,17 @@ LAYERS = [
     ("k3 2048->256 @32 g1", 20, 32, 32, 2048, 256, 3, 1, 1, False),
     ("q2 1024->128 @64 M16", 16, 64, 64, 1024, 128, 3, 1, 1, False),
     ("q3 2048->256 @32 M32", 32, 32, 32, 2048, 256, 3, 1, 1, False),
+    # a rank's share of cfg 3 (1 agent x B = 8)
+    ("r3 256->256 @32 M8 res", 8, 32, 32, 256, 256, 3, 1, 1, True),
+    ("r4 512->512 @16 M8 res", 8, 16, 16, 512, 512, 3, 1, 1, True),
 ]
 VALID = {  # variant -> (BM, BN, BK)
     0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
     30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64), 52: (64, 64, 64), 54: (128, 64, 64),
     80: (128, 128, 64), 81: (128, 64, 64), 83: (128, 64, 64), 93: (128, 64, 64), 94: (128, 64, 64),      # conv_wreg.inl forms
+    95: (128, 64, 64), 96: (128, 64, 64),                                                                # ... 32 channels per wave
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 52: (4, 16), 54: (8, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 52: (4, 16), 54: (8, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16), 95: (8, 16), 96: (8, 16)}
 
 
 def main():
