@@ -36,6 +36,7 @@ def _fold_bn(bn, conv_bias=None):
 
 
 _USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
+_VALUE_LAG = int(os.environ.get('W2C_VALUE_LAG', '0'))   # A/B: the value chain starts behind block k of the policy chain (0 = together)
 _HEADS_AFTER_JOIN = bool(os.environ.get('W2C_HEADS_AFTER_JOIN'))
 # the remaining A/B switches, read once at import (never on the launch path)
 _NO_SPLITK = bool(os.environ.get('W2C_NO_SPLITK'))
@@ -304,13 +305,19 @@ class TrunkPlan:
         _stamp(0)
         side.wait_stream(main)
 
+        lag_ev = None
+
         def chain(g):
+            nonlocal lag_ev
             _stamp(1 + g)
             q, off = p, g * cin0
             for bi, (c1, c2, ds) in enumerate(plans[g][0]):
                 t, idt = _block_front(c1, ds, q, x_ch_off=off)       # the chain's first block is a stride-2 block: idt is its own
                 q, off = c2.run(t, residual=idt), 0
                 _stamp(8 + 8 * g + bi)
+                if g == 1 and _VALUE_LAG and bi == _VALUE_LAG - 1:
+                    lag_ev = torch.cuda.Event()
+                    lag_ev.record(torch.cuda.current_stream(p.device))
             if squeezer_out is not None:
                 plans[g][1].run(q, out_groups=[squeezer_out[g]])
             else:
@@ -322,6 +329,8 @@ class TrunkPlan:
             chain(1)
             if policy_next is not None:            # the policy chain goes straight on (policy convs) beside the value chain
                 state = policy_next[0](sq if squeezer_out is None else squeezer_out[1])
+        if lag_ev is not None:                     # W2C_VALUE_LAG=k (A/B): the value chain starts behind the policy chain's block k
+            main.wait_event(lag_ev)
         chain(0)
         vres = value_next(sq if squeezer_out is None else squeezer_out[0]) if value_next is not None else None
         _stamp(26)
