@@ -476,10 +476,10 @@ def main():
     # its graph at ~2.97 ms per step WHATEVER the workload (cfg 2: 1.07 ms of kernels; a cfg-3 rank: 0.6) -- a fixed stall per replay on
     # the host/queue side, for the whole life of that process, never reproduced on demand (tools/hunt_slow_mode.sh: 0 of 28).  The
     # in-kernel launch spans of the same process tell it apart from a slow device: they stay at their usual length.  A run whose step
-    # takes more than twice the chip time of its own kernels is therefore repeated ONCE in a fresh process; the line printed is that
+    # takes more than twice the chip time of its own kernels (and >= 1 ms more) is therefore repeated ONCE in a fresh process; the line printed is that
     # run's, complete and timed as the contract says, and says so (`retry`).  --no-retry reports the stalled run as it is.
     busy = roofline.get("kernel_ms_per_step") if isinstance(roofline, dict) else None
-    stalled = bool(busy) and ms_per_step > 2.0 * busy + 0.2
+    stalled = bool(busy) and ms_per_step > 2.0 * busy + 0.2 and ms_per_step - busy > 1.0      # (>= 1 ms per step with the chip idle)
     if world == 1 and not args.no_retry and (stalled or os.environ.get("W2C_BENCH_FORCE_RETRY") == "1"):   # (the env switch: tests)
         import subprocess
         if dist.is_initialized():
