@@ -377,6 +377,10 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     launch_form = getattr(fwd, "launch_form", "")            # what the TIMED steps ran as (later legs may take other paths)
+    try:                                                     # replay times of the graph instantiations the engine auditioned (engine._audition)
+        audition_ms = getattr(model._engine_for(x, fwd._engine_cls), "audition_ms", None)
+    except Exception:                                        # noqa: BLE001
+        audition_ms = None
     images_per_step = B * N
     value = images_per_step * args.steps / elapsed
 
@@ -470,14 +474,20 @@ def main():
                                        else "3 hip-graph segments + eager collectives"))
                               if model.use_hip_graph else "eager"),
                   roofline=roofline, host_enqueue=host_enqueue)
+    if audition_ms:
+        result["config"]["graph_audition_ms"] = audition_ms
 
-    # ---- guard: the rare slow-launch state ---------------------------------------------------------------------------------------
+    # ---- guard: the slow-replay state ----------------------------------------------------------------------------------------------
     # Twice in ~90 fresh-process runs of round 4 (gpurun_out/r04_e_rank_shapes_raw.txt line 1; an A/B loop earlier) a process replayed
-    # its graph at ~2.97 ms per step WHATEVER the workload (cfg 2: 1.07 ms of kernels; a cfg-3 rank: 0.6) -- a fixed stall per replay on
-    # the host/queue side, for the whole life of that process, never reproduced on demand (tools/hunt_slow_mode.sh: 0 of 28).  The
-    # in-kernel launch spans of the same process tell it apart from a slow device: they stay at their usual length.  A run whose step
-    # takes more than twice the chip time of its own kernels (and >= 1 ms more) is therefore repeated ONCE in a fresh process; the line printed is that
-    # run's, complete and timed as the contract says, and says so (`retry`).  --no-retry reports the stalled run as it is.
+    # its graph at ~2.97 ms per step WHATEVER the workload (cfg 2: 1.07 ms of kernels; a cfg-3 rank: 0.6), with the in-kernel launch
+    # spans at their usual length: the chip idles between launches.  Cause, found late in the round (tools/graph_audition.py,
+    # tools/ab_hwq.sh): how a graph instantiation's parallel branches land on the runtime's streams / hardware queues -- with
+    # GPU_MAX_HW_QUEUES=5 the first two captures of EVERY process replay at 2.0-2.1 ms and later captures of the same graph at 1.10.
+    # The single-GPU engine now auditions up to three instantiations and keeps the fastest (engine.CommEngine._audition;
+    # config.graph_audition_ms in this line), which removes the state where it is per instantiation.  This guard stays as the backstop
+    # for whatever is per process: a run whose step takes more than twice the chip time of its own kernels (and >= 1 ms more) is
+    # repeated ONCE in a fresh process; the line printed is that run's, complete and timed as the contract says, and says so (`retry`).
+    # --no-retry reports the stalled run as it is.
     busy = roofline.get("kernel_ms_per_step") if isinstance(roofline, dict) else None
     stalled = bool(busy) and ms_per_step > 2.0 * busy + 0.2 and ms_per_step - busy > 1.0      # (>= 1 ms per step with the chip idle)
     if world == 1 and not args.no_retry and (stalled or os.environ.get("W2C_BENCH_FORCE_RETRY") == "1"):   # (the env switch: tests)
