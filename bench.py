@@ -378,7 +378,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     launch_form = getattr(fwd, "launch_form", "")            # what the TIMED steps ran as (later legs may take other paths)
     try:                                                     # replay times of the graph instantiations the engine auditioned (engine._audition)
-        audition_ms = getattr(model._engine_for(x, fwd._engine_cls), "audition_ms", None)
+        audition_ms = getattr(fwd, "audition_ms", None) or getattr(model._engine_for(x, fwd._engine_cls), "audition_ms", None)
     except Exception:                                        # noqa: BLE001
         audition_ms = None
     images_per_step = B * N
