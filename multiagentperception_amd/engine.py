@@ -36,7 +36,7 @@ def _fold_bn(bn, conv_bias=None):
 
 
 _USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
-_GRAPH_AUDITION = int(os.environ.get('W2C_GRAPH_AUDITION', '3'))   # captures a one-graph forward may audition (CommEngine._audition)
+_GRAPH_AUDITION = int(os.environ.get('W2C_GRAPH_AUDITION', '4'))   # captures a one-graph forward may audition (CommEngine._audition)
 _VALUE_LAG = int(os.environ.get('W2C_VALUE_LAG', '0'))   # A/B: the value chain starts behind block k of the policy chain (0 = together)
 _HEADS_AFTER_JOIN = bool(os.environ.get('W2C_HEADS_AFTER_JOIN'))
 # the remaining A/B switches, read once at import (never on the launch path)
@@ -775,13 +775,14 @@ class CommEngine:
         return out, prob, action, nnz
 
     def _audition(self, x, B, N, mode, labels, confusion, out):
-        """Capture the forward up to three times and keep the instantiation that replays fastest.  Why: how a graph's parallel branches
-        land on the runtime's streams / hardware queues is decided per instantiation, and a bad assignment -- dependent launches on
-        different queues, every edge a cross-queue signal -- replays the SAME graph 2-3x slower for its whole life (tools/graph_audition.py:
-        with GPU_MAX_HW_QUEUES=5 the first two captures of a process run at 2.0-2.1 ms, the later ones at 1.10; with the default 4 about 2 %
-        of fresh processes drew it: the 2.97 ms state bench.py guards against).  Two captures that agree within 5 % end the audition; a
-        third is taken when they do not.  Costs two or three captures (~0.1 s) at the first forward of a shape.  W2C_GRAPH_AUDITION=1:
-        take the first capture as it comes.  self.audition_ms = the candidates' replay times."""
+        """Capture the forward W2C_GRAPH_AUDITION (4) times and keep the instantiation that replays fastest.  Why: how a graph's parallel
+        branches land on the runtime's streams / hardware queues is decided per instantiation, and a bad assignment replays the SAME
+        graph slower for its whole life -- 2-3x when dependent launches sit on different queues (every edge a cross-queue signal), ~1.35x
+        when the two trunk chains share one (tools/graph_audition.py: with GPU_MAX_HW_QUEUES=5 the first two captures of a process run
+        at 2.0-2.1 ms, the later ones at 1.10; with the default 4 about 2 % of fresh processes drew the bad one: the 2.97 ms state
+        bench.py guards against).  Consecutive instantiations cycle through the assignments, so a few candidates see them all; no
+        early exit (two slow candidates in a row agree with each other, too).  Costs ~0.15 s at the first forward of a shape.
+        W2C_GRAPH_AUDITION=1: take the first capture as it comes.  self.audition_ms = the candidates' replay times."""
         dev = x.device
         gt, hist = confusion if confusion is not None else (None, None)
         scratch_hist = None if hist is None else torch.zeros_like(hist)
@@ -807,8 +808,6 @@ class CommEngine:
             times.append(round(t, 4))
             if best is None or t < best[0]:
                 best = (t, entry)
-            if i >= 1 and max(times[0], times[1]) <= 1.05 * min(times[0], times[1]):
-                break
         self.audition_ms = times
         return best[1]
 

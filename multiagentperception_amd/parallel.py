@@ -352,8 +352,6 @@ class AgentParallelForward:
                 times.append(round(t, 4))
                 if best is None or t < best[0]:
                     best = (t, cand)
-                if i >= 1 and max(times[0], times[1]) <= 1.05 * min(times[0], times[1]):
-                    break
             self.audition_ms = times
             ent = st.graphs["whole:" + inference] = best[1]
         graph, slots, pack = ent
