@@ -478,7 +478,7 @@ def main():
         result["config"]["graph_audition_ms"] = audition_ms
 
     # ---- guard: the slow-replay state ----------------------------------------------------------------------------------------------
-    # Twice in ~90 fresh-process runs of round 4 (gpurun_out/r04_e_rank_shapes_raw.txt line 1; an A/B loop earlier) a process replayed
+    # Twice in ~90 fresh-process runs of round 4 (profiles/r04_rank_shapes.txt, first raw line of job r04_e; an A/B loop earlier) a process replayed
     # its graph at ~2.97 ms per step WHATEVER the workload (cfg 2: 1.07 ms of kernels; a cfg-3 rank: 0.6), with the in-kernel launch
     # spans at their usual length: the chip idles between launches.  Cause, found late in the round (tools/graph_audition.py,
     # tools/ab_hwq.sh): how a graph instantiation's parallel branches land on the runtime's streams / hardware queues -- with
