@@ -199,8 +199,23 @@ int w2c_conv_s2_block_wreg(const uint16_t* x, int M, int H, int W, int Cin, int 
                            int Cout, int groups, uint16_t* t_bf16, int t_cstride, uint16_t* idt_bf16, int idt_cstride,
                            int form, w2c_stream_t stream);
 
+/* ---- the front of the FIRST stride-2 block (layer2.0: Cin = 64 -> Cout = 128 per group) on a persistent weights-stationary kernel
+ * (csrc/conv_s2regh.inl; round 4): every wave keeps its 32 output channels' conv1 weights in registers, the 17 x 17-pixel input patch of
+ * an 8 x 8 output tile is staged once per workgroup as four phase images, double-buffered across the tiles of a persistent workgroup.
+ * H, W even, (H/2) % 8 == 0, (W/2) % 8 == 0; w2c_conv_s2_front_c64_supported() = offered for this geometry (a function of the
+ * geometry and the W2C_S2REGH switch only, never of M or the group count).  w3frag / w1frag as for w2c_conv_s2_block_wreg.
+ * Outputs: t = relu(bn1(conv1(x))), idt = bn_d(downsample(x)), bf16, group g at element offset g * *_group_stride (128 = side by side
+ * inside one [M][H/2][W/2][*_cstride] tensor; M * H/2 * W/2 * 128 = one compact slab per group).  Same K order as
+ * w2c_conv_s2_block: both outputs are bit-identical to it. */
+int w2c_conv_s2_front_c64_supported(int H, int W, int Cin, int Cout);
+int w2c_conv_s2_front_c64(const uint16_t* x, int M, int H, int W, int x_cstride,
+                          const uint16_t* w3frag, const float* scale3, const float* shift3,
+                          const uint16_t* w1frag, const float* scale1, const float* shift1, int groups,
+                          uint16_t* t_bf16, int t_cstride, long long t_group_stride,
+                          uint16_t* idt_bf16, int idt_cstride, long long idt_group_stride, w2c_stream_t stream);
+
 /* ---- debug / A-B switches ("W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND", "W2C_STEM_WAVES",
- * "W2C_WGRAD_PATCH", ... "W2C_S2WREG_FORM": csrc/w2c_common.h lists them all).  The library reads the environment variables of the same names ONCE, when it is loaded; no launch path calls
+ * "W2C_WGRAD_PATCH", ... "W2C_S2WREG_FORM", "W2C_S2REGH": csrc/w2c_common.h lists them all).  The library reads the environment variables of the same names ONCE, when it is loaded; no launch path calls
  * getenv().  w2c_set_option changes a switch at run time (returns W2C_E_ARG for an unknown name), w2c_get_option reads it (-1 unknown). */
 int w2c_set_option(const char* name, int value);
 int w2c_get_option(const char* name);

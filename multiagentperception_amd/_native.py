@@ -43,6 +43,8 @@ SIGNATURES = {
                           _vp, _i, _vp],
     "w2c_conv_s2_block_wreg_supported": [_i, _i, _i, _i],
     "w2c_conv_s2_block_wreg": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp],
+    "w2c_conv_s2_front_c64_supported": [_i, _i, _i, _i],
+    "w2c_conv_s2_front_c64": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _vp, _i, _ll, _vp],
     "w2c_set_option": [_c.c_char_p, _i],
     "w2c_get_option": [_c.c_char_p],
     "w2c_debug_block_phases": [_vp],

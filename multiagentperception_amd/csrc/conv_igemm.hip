@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 0, 0};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 0, 0, 1};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -112,6 +112,7 @@ struct ConvArgs {
     const float* shift2;
     uint16_t* y2;              // bf16, groups side by side, pixel stride y2cs; no ReLU, no residual
     int y2cs;
+    long long y2gs;            // conv_s2regh.inl: element offset between the groups' slabs of y2 (ygs is that of y)
     int xcd2d;                 // patch kernel, 2 groups on a flattened grid: XCD -> (group, half of the tiles, half of the channel tiles)
 };
 
@@ -1927,6 +1928,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
 #include "conv_wreg.inl"
 #include "conv_regh.inl"
 #include "conv_s2wreg.inl"
+#include "conv_s2regh.inl"
 
 template <int BM, int BN, int BK, int STAGES>
 constexpr int conv_lds_bytes() {
@@ -2389,7 +2391,7 @@ int fill_args(ConvArgs& a, const void* x, int M, int H, int W, int Cin, int x_cs
     a.n_split = 1;
     a.ygs = y_group_stride;
     a.y8 = y8; a.y8cs = y8_cstride; a.q8 = y8 ? 1.f / y8_scale : 1.f;
-    a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.y2 = nullptr; a.y2cs = 0;
+    a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.y2 = nullptr; a.y2cs = 0; a.y2gs = 0;
     return W2C_OK;
 }
 
@@ -2652,6 +2654,29 @@ extern "C" int w2c_conv_s2_block_wreg(const uint16_t* x, int M, int H, int W, in
         case 4: return launch_s2wreg<1, 2, 2>(a, groups, s);
         default: return W2C_E_ARG;
     }
+}
+
+// Front of the first stride-2 BasicBlock (Cin = 64 -> Cout = 128 per group) on the persistent weights-stationary kernel (conv_s2regh.inl).
+// Offered from the layer geometry only (never from M or the group count: a sharded batch takes the same kernel as the whole one).
+extern "C" int w2c_conv_s2_front_c64_supported(int H, int W, int Cin, int Cout) {
+    return w2c_option(W2C_OPT_S2REGH) != 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && ((H / 2) % 8) == 0 && ((W / 2) % 8) == 0 && Cin == 64 &&
+           Cout == 128;
+}
+extern "C" int w2c_conv_s2_front_c64(const uint16_t* x, int M, int H, int W, int x_cstride,
+                                     const uint16_t* w3frag, const float* scale3, const float* shift3,
+                                     const uint16_t* w1frag, const float* scale1, const float* shift1, int groups,
+                                     uint16_t* t_bf16, int t_cstride, long long t_group_stride,
+                                     uint16_t* idt_bf16, int idt_cstride, long long idt_group_stride, w2c_stream_t stream) {
+    w2c_clear_error();
+    ConvArgs a;
+    if (t_group_stride <= 0 || idt_group_stride <= 0 || (idt_group_stride % 8) != 0) return W2C_E_ARG;
+    const int rc = fill_args(a, x, M, H, W, 64, x_cstride, w3frag, 128, 3, 2, groups, scale3, shift3, nullptr, 1, t_bf16, t_cstride, 0,
+                             /*zero_page=*/x, t_group_stride);
+    if (rc != W2C_OK) return rc;
+    if (!t_bf16 || !w1frag || !scale1 || !shift1 || !idt_bf16 || (idt_cstride % 8) != 0 || idt_cstride < (idt_group_stride == 128 ? groups : 1) * 128)
+        return W2C_E_ARG;
+    a.w2 = w1frag; a.scale2 = scale1; a.shift2 = shift1; a.y2 = idt_bf16; a.y2cs = idt_cstride; a.y2gs = idt_group_stride;
+    return launch_s2regh(a, groups, reinterpret_cast<hipStream_t>(stream));
 }
 
 // One wave: C[32][32] (f32, row-major) = A[32][64] * B[32][64]^T with e4m3 operands through the MX-scaled MFMA with unit

@@ -105,6 +105,12 @@ class ConvPlan:
             elif self.ksize == 1:
                 self.wfrag_s2 = ops.pack_w1frag(self.w, self.cin)
 
+        # layer2.0's two convs (64 -> 128, stride 2) keep fragment-ordered copies for w2c_conv_s2_front_c64 (conv_s2regh.inl)
+        self.wfrag_c64 = None
+        if (_USE_WREG and self.stride == 2 and self.cin == 64 and self.cout == 128 and self.w.is_cuda
+                and ops.conv_s2_front_c64_supported(16, 16, 64, 128)):
+            self.wfrag_c64 = ops.pack_wfrag_device(self.w, 64) if self.ksize == 3 else ops.pack_w1frag(self.w, 64) if self.ksize == 1 else None
+
     def run(self, x, x_ch_off=0, residual=None, out_f32=False, out_groups=None, out=None, out_ch_off=0):
         far = False                                  # group slabs further apart than the kernel's 32-bit output offsets reach
         if out_groups is not None and len(out_groups) > 1:
@@ -157,6 +163,11 @@ class Fp8ConvPlan:
                             out_groups=out_groups, out=out, out_ch_off=out_ch_off)
 
 
+def _front_c64_ok(c1, ds, x):
+    return (ds is not None and getattr(c1, "wfrag_c64", None) is not None and getattr(ds, "wfrag_c64", None) is not None
+            and ops.conv_s2_front_c64_supported(x.shape[1], x.shape[2], c1.cin, c1.cout))
+
+
 def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
     """conv1 (+ the 1x1/s2 downsample of a stride-2 block) of a BasicBlock on x -> (t, identity).  Stride-2 blocks run
     both convs as ONE launch (w2c_conv_s2_block: the 3x3's centre tap IS the 1x1's input); W2C_NO_DUAL=1 keeps the two
@@ -176,6 +187,9 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
             return (c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1],
                     ds.run(x, x_ch_off=x_ch_off)[0])
         return c1.run(x, x_ch_off=x_ch_off), ds.run(x, x_ch_off=x_ch_off)
+    if _front_c64_ok(c1, ds, x) and not f8:
+        # layer2.0 (64 -> 128): persistent weights-stationary kernel, bit-identical to w2c_conv_s2_block
+        return ops.conv_s2_front_c64(x, x_ch_off, c1.wfrag_c64, c1.scale, c1.shift, ds.wfrag_c64, ds.scale, ds.shift, c1.groups)
     if (not f8 and getattr(c1, "wfrag_s2", None) is not None and getattr(ds, "wfrag_s2", None) is not None
             and ops.conv_s2_block_wreg_supported(x.shape[1], x.shape[2], c1.cin, c1.cout)):
         return ops.conv_s2_block_wreg(x, x_ch_off, c1.cin, c1.wfrag_s2, c1.scale, c1.shift, ds.wfrag_s2, ds.scale, ds.shift,
@@ -295,6 +309,13 @@ class TrunkPlan:
             p = c2.run(t, residual=idt)
         plans = self._single_trunk_plans(split_from)
         cin0 = self.blocks[split_from][0].cin
+        # layer2.0's front (conv1 3x3/s2 + the 1x1/s2 downsample, 64 -> 128) of BOTH trunks as one two-group launch of the persistent
+        # weights-stationary kernel (conv_s2regh.inl) before the fork: as two one-group launches at the head of the two chains the
+        # polyphase ring kernel takes 59 us for the pair (latency-bound: 2.8 TB/s on 168 MB).  Outputs = one compact slab per trunk.
+        front = None
+        c1f, _, dsf = self.blocks[split_from]
+        if _front_c64_ok(c1f, dsf, p) and not _NO_DUAL:
+            front = ops.conv_s2_front_c64(p, 0, c1f.wfrag_c64, c1f.scale, c1f.shift, dsf.wfrag_c64, dsf.scale, dsf.shift, c1f.groups, slabs=True)
         feat = self.squeezer.cout
         M, Hs, Ws, _ = p.shape
         for _, _, ds in self.blocks[split_from:]:
@@ -313,7 +334,10 @@ class TrunkPlan:
             _stamp(1 + g)
             q, off = p, g * cin0
             for bi, (c1, c2, ds) in enumerate(plans[g][0]):
-                t, idt = _block_front(c1, ds, q, x_ch_off=off)       # the chain's first block is a stride-2 block: idt is its own
+                if bi == 0 and front is not None:
+                    t, idt = front[0][g], front[1][g]
+                else:
+                    t, idt = _block_front(c1, ds, q, x_ch_off=off)   # the chain's first block is a stride-2 block: idt is its own
                 q, off = c2.run(t, residual=idt), 0
                 _stamp(8 + 8 * g + bi)
                 if g == 1 and _VALUE_LAG and bi == _VALUE_LAG - 1:

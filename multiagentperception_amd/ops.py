@@ -605,6 +605,43 @@ def conv_s2_block_wreg(x, x_ch_off, cin, w3frag, scale3, shift3, w1frag, scale1,
     return t16, idt
 
 
+def conv_s2_front_c64_supported(H, W, cin, cout):
+    return bool(_native.lib().w2c_conv_s2_front_c64_supported(int(H), int(W), int(cin), int(cout)))
+
+
+def conv_s2_front_c64(x, x_ch_off, w3frag, scale3, shift3, w1frag, scale1, shift1, groups, slabs=False):
+    """Front of the first stride-2 BasicBlock (64 -> 128 per group) on the persistent weights-stationary kernel (include/w2c_hip.h
+    w2c_conv_s2_front_c64): returns (t, idt), bf16.  slabs=False: [M, H/2, W/2, groups*128], groups side by side (w2c_conv_s2_block's
+    layout); slabs=True: [groups, M, H/2, W/2, 128], one compact tensor per group (each trunk's chain goes on with a one-group tensor)."""
+    dev = _need_gpu(x, w3frag, scale3, shift3, w1frag, scale1, shift1)
+    if x.dtype != BF16 or w3frag.dtype != BF16 or w1frag.dtype != BF16:
+        raise W2CError("conv_s2_front_c64: bf16 operands")
+    M, H, W, xcs = x.shape
+    if x_ch_off < 0 or x_ch_off + groups * 64 > xcs:
+        raise W2CError("conv_s2_front_c64: channels outside the tensor")
+    if tuple(w3frag.shape) != (groups, 128, 9 * 64) or tuple(w1frag.shape) != (groups, 128, 64):
+        raise W2CError("conv_s2_front_c64: weight shapes")
+    Ho, Wo = H // 2, W // 2
+    if slabs:
+        shape, cs, gs = (groups, M, Ho, Wo, 128), 128, M * Ho * Wo * 128
+    else:
+        shape, cs, gs = (M, Ho, Wo, groups * 128), groups * 128, 128
+    t16 = torch.empty(shape, dtype=BF16, device=dev)
+    idt = torch.empty(shape, dtype=BF16, device=dev)
+    timer = getattr(_tls, "conv_timer", None)
+    tok = timer.begin(dev) if timer is not None else None
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv_s2_front_c64(x.data_ptr() + 2 * x_ch_off, M, H, W, xcs, _p(w3frag), _p(scale3), _p(shift3),
+                                                  _p(w1frag), _p(scale1), _p(shift1), groups, _p(t16), cs, gs, _p(idt), cs, gs,
+                                                  _stream(dev)),
+              "w2c_conv_s2_front_c64")
+    if timer is not None:
+        flops = 2.0 * M * Ho * Wo * 128 * (10 * 64) * groups
+        nbytes = M * H * W * 64 * groups * 2 + M * Ho * Wo * 128 * groups * 4 + groups * 128 * 10 * 64 * 2
+        timer.end(tok, dev, flops, (M * Ho * Wo, 64, 128, "3+1", 2, groups), nbytes)
+    return t16, idt
+
+
 def conv_block_c64(x, w1, scale1, shift1, w2, scale2, shift2, groups, out=None, max_workgroups=0):
     """A whole 64-channel stride-1 BasicBlock in one launch (include/w2c_hip.h w2c_conv_block_c64):
     y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).  x bf16 NHWC [M,H,W,cs], group g in channels [64g, 64g+64);

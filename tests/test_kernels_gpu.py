@@ -1239,6 +1239,73 @@ def test_s2_block_front_wreg_is_independent_of_image_count_and_groups_and_repeat
             assert torch.equal(t2, t) and torch.equal(i2, idt)
 
 
+S2R_CASES = [
+    # (M, H, W, G, x channel pad): 64 -> 128 per group
+    (3, 32, 32, 1, 0),        # 2 x 2 output tiles per image (top / left halo tiles and interior ones), one group
+    (2, 64, 32, 2, 0),        # both trunks' layout: two groups read one 128-channel tensor
+    (1, 16, 16, 2, 64),       # one tile per image, x wider than the conv reads
+    (5, 48, 80, 1, 0),        # tile counts that do not divide the workgroup count
+]
+
+
+@pytest.mark.parametrize("case", S2R_CASES, ids=lambda c: "m%d-%dx%d-g%d-p%d" % c)
+@pytest.mark.parametrize("slabs", [False, True])
+def test_s2_front_c64_persistent_kernel_is_bit_identical_to_the_ring_kernel(case, slabs):
+    """w2c_conv_s2_front_c64 (csrc/conv_s2regh.inl): layer2.0's conv1 3x3/s2 + 1x1/s2 downsample with stationary weights on persistent
+    workgroups -- same K order as w2c_conv_s2_block, so BOTH outputs equal it bit for bit (side-by-side and per-group-slab layouts);
+    conv1 also within the usual bound of an fp32 conv."""
+    from multiagentperception_amd import ops
+    M, H, W, G, xpad = case
+    x, w3, w1, sc3, sh3, sc1, sh1 = _s2w_setup((0, M, H, W, 64, 128, G, xpad), 3000 + sum(case))
+    assert ops.conv_s2_front_c64_supported(H, W, 64, 128)
+    f3, f1 = ops.pack_wfrag_device(w3, 64), ops.pack_w1frag(w1, 64)
+    t, idt = ops.conv_s2_front_c64(x, 0, f3, sc3, sh3, f1, sc1, sh1, G, slabs=slabs)
+    t0, _, idt0 = ops.conv_s2_block(x, 0, 64, w3, sc3, sh3, w1, sc1, sh1, 128, G)
+    torch.cuda.synchronize()
+    if slabs:
+        assert t.shape == (G, M, H // 2, W // 2, 128)
+        t = torch.cat(list(t), dim=-1)
+        idt = torch.cat(list(idt), dim=-1)
+    assert torch.equal(idt, idt0)
+    assert torch.equal(t, t0)
+    xc, w3c = x.float().cpu(), w3.float().cpu()
+    for g in range(G):
+        xin = xc[..., g * 64:(g + 1) * 64].permute(0, 3, 1, 2)
+        wg = w3c[g].reshape(128, 3, 3, 64).permute(0, 3, 1, 2)
+        ref = F.conv2d(xin, wg, None, stride=2, padding=1)
+        ref = F.relu(ref * sc3.cpu()[g * 128:(g + 1) * 128].view(1, -1, 1, 1) + sh3.cpu()[g * 128:(g + 1) * 128].view(1, -1, 1, 1))
+        np.testing.assert_allclose(_to_nchw(t, g * 128, 128).numpy(), ref.numpy(), atol=2e-3, rtol=2 ** -7)
+
+
+def test_s2_front_c64_is_independent_of_image_count_groups_and_workgroup_count_and_repeatable():
+    """persistent workgroups on runs of tiles: the result of a tile does not depend on which workgroup computes it or what it computed
+    before (odd workgroup counts through W2C_REGH_WGS: runs that start mid-image, a single workgroup walking everything), image i of a
+    batch equals that image alone, group g of a two-group launch equals the one-group launch, 40 repeats are identical (race screen
+    for the double-buffered patch hand-off and the hand-counted vmcnt)."""
+    from multiagentperception_amd import ops, _native
+    case = (0, 5, 32, 64, 64, 128, 2, 0)
+    x, w3, w1, sc3, sh3, sc1, sh1 = _s2w_setup(case, 77)
+    f3, f1 = ops.pack_wfrag_device(w3, 64), ops.pack_w1frag(w1, 64)
+    t, idt = [o.clone() for o in ops.conv_s2_front_c64(x, 0, f3, sc3, sh3, f1, sc1, sh1, 2)]
+    for i in (0, 4):
+        t1, i1 = ops.conv_s2_front_c64(x[i:i + 1].contiguous(), 0, f3, sc3, sh3, f1, sc1, sh1, 2)
+        assert torch.equal(t1[0], t[i]) and torch.equal(i1[0], idt[i])
+    tg, ig = ops.conv_s2_front_c64(x, 64, f3[1:].contiguous(), sc3[128:].contiguous(), sh3[128:].contiguous(),
+                                   f1[1:].contiguous(), sc1[128:].contiguous(), sh1[128:].contiguous(), 1)
+    assert torch.equal(tg, t[..., 128:]) and torch.equal(ig, idt[..., 128:])
+    for wgs in (1, 3, 7, 13):
+        old = _native.set_option("W2C_REGH_WGS", wgs)
+        try:
+            t2, i2 = ops.conv_s2_front_c64(x, 0, f3, sc3, sh3, f1, sc1, sh1, 2)
+            torch.cuda.synchronize()
+        finally:
+            _native.set_option("W2C_REGH_WGS", old)
+        assert torch.equal(t2, t) and torch.equal(i2, idt), wgs
+    for _ in range(40):
+        t2, i2 = ops.conv_s2_front_c64(x, 0, f3, sc3, sh3, f1, sc1, sh1, 2)
+        assert torch.equal(t2, t) and torch.equal(i2, idt)
+
+
 def test_conv3x3_wreg_32_channel_wave_forms_are_bit_identical_to_the_64_channel_ones():
     """forms 95 / 96 put twice the waves on the same workgroup tile (32 channels per wave) for launches too small to fill the chip's
     wave slots; same K groups and reduction order, so the choice (which depends on the launch size) never shows in the bits"""
