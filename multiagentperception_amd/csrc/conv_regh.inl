@@ -309,7 +309,10 @@ int launch_regh(ConvArgs& a, int groups, hipStream_t s) {
         attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const long tiles = (long)a.M * (a.H / 8) * (a.W / 16);
-    long wgs = (2L * n_cu[dev & 63] + groups - 1) / groups;      // two 4-wave workgroups per CU, split over the groups
+    // one group: two 4-wave workgroups per CU.  Two groups (both trunks' layer1): ONE workgroup per CU in total -- these launches move
+    // 168 / 252 MB at 3.5-4.6 TB/s, the second wave per SIMD buys 2 % of the launch (53.2 -> 54.3 us) and costs power the rest of the
+    // forward pays for: 1.054 -> 1.040 ms per forward with half the workgroups (profiles/r04_s2_front_c64.txt, W2C_REGH_WGS A/B)
+    long wgs = groups == 1 ? 2L * n_cu[dev & 63] : (n_cu[dev & 63] + groups - 1) / groups;
     const int opt = w2c_option(W2C_OPT_REGH_WGS);
     if (opt > 0) wgs = opt;
     if (wgs > tiles) wgs = tiles;

@@ -314,7 +314,9 @@ int launch_s2regh(ConvArgs& a, int groups, hipStream_t s) {
         attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const long tiles = (long)a.M * (a.Ho / 8) * (a.Wo / 8);
-    long wgs = (2L * n_cu[dev & 63] + groups - 1) / groups;      // two 4-wave workgroups per CU, split over the groups
+    // one group: two 4-wave workgroups per CU; several groups: ONE workgroup per CU in total -- the launch is HBM-bound then (4.2 TB/s
+    // at cfg 2) and half the workgroups are 3-5 % faster (tools/bench_s2_front_c64.py: 37.9 vs 39.8 us, M = 8: 20.3 vs 21.1, 1024^2: 31.1 vs 32.7)
+    long wgs = groups == 1 ? 2L * n_cu[dev & 63] : (n_cu[dev & 63] + groups - 1) / groups;
     const int opt = w2c_option(W2C_OPT_REGH_WGS);
     if (opt > 0) wgs = opt;
     if (wgs > tiles) wgs = tiles;
