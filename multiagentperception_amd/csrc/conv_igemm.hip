@@ -39,7 +39,7 @@ static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2P
                                                         "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 0, 0, 1};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 0, 1};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -2619,6 +2619,9 @@ extern "C" int w2c_conv_s2_block(const void* x, int x_is_fp8, int M, int H, int 
 // group: 26.0 vs 29.5, 25.0 vs 29.5 us; layer2.0 32.1 vs 32.6) but its workgroups live as long (prologue 2.5-3 us + reduction +
 // downsample pass + stores around a main loop that is 1.3-1.7x faster), so beside the other trunk chain the forward does not move
 // (1.0484 vs 1.0485 ms, 3 interleaved pairs; rank shapes of cfg 3 / cfg 4 the same) -- profiles/r04_s2_front_wreg.txt.
+// Round 4, third session: DEFAULT (form 1) since the persistent two-group launches went to one workgroup per CU: with the
+// front of the forward burning less power the faster main loop shows -- 4 interleaved pairs, bench.py --steps 100: 1.0222 1.0074 1.0164
+// 1.0187 (ring kernel) vs 1.0054 1.0049 1.0065 1.0009 ms (form 1); layer2.0 (Cin = 64) goes to conv_s2regh.inl before this is asked.
 static int s2wreg_form(int H, int W, int Cin, int Cout) {
     if (H <= 0 || W <= 0 || (H & 1) || (W & 1) || ((H / 2) % 8) != 0 || ((W / 2) % 16) != 0 || (Cin % 64) != 0 || Cin > 256 || (Cout % 64) != 0)
         return 0;

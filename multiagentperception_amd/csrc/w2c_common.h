@@ -108,7 +108,7 @@ enum W2COption {
     W2C_OPT_REGH_WGS,         // > 0: workgroups per group of the two-waves-per-SIMD layer1 kernel (tests: odd run lengths)
     W2C_OPT_REGH_FORM,        // 0 (default) | 1 | 2 | 3: A/B forms of the two-waves-per-SIMD layer1 kernel (conv_regh.inl)
     W2C_OPT_L1_FORM,          // layer1 (Cin = Cout = 64) through w2c_conv3x3_wreg_bf16: 54 (default) = conv3x3_c64_regh_kernel | 0 = not offered
-    W2C_OPT_S2WREG_FORM,      // stride-2 block fronts (conv_s2wreg.inl): 0 (default) = not offered | 1 .. 4: that kernel form wherever it fits
+    W2C_OPT_S2WREG_FORM,      // stride-2 block fronts (conv_s2wreg.inl): 1 (default) .. 4: that kernel form wherever it fits | 0 = not offered (ring kernel)
     W2C_OPT_WREG_SMALL,       // 0 (default) = never | n: wreg launches with fewer 128-px x 64-ch tiles than n take the 32-channels-per-wave form (96)
     W2C_OPT_S2REGH,           // 1 (default) | 0: the first stride-2 block front (64 -> 128) on the persistent weights-stationary kernel (conv_s2regh.inl)
     W2C_OPT_COUNT
