@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH", "W2C_UPS_LDS_KB"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 0, 1};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 0, 1, 0};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);

@@ -433,7 +433,11 @@ extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, in
     w2c_clear_error();
     if (!low || !out || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || low_cstride < n_classes) return W2C_E_ARG;
     if ((size_t)h * w * 4 > 64 * 1024) return W2C_E_ARG;
-    hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), (size_t)h * w * 4,
+    // W2C_UPS_LDS_KB (A/B): pad the workgroup's LDS request to that many KB = cap the workgroups resident per CU (a write-bound launch:
+    // does it need 8 workgroups per CU, and what do they cost the next forward's front in power?)
+    size_t lds = (size_t)h * w * 4;
+    if (const int kb = w2c_option(W2C_OPT_UPS_LDS_KB); kb > 0 && (size_t)kb * 1024 > lds && kb <= 64) lds = (size_t)kb * 1024;
+    hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), low, h, w, low_cstride, n_classes, out);
     return w2c_launch_status();
 }

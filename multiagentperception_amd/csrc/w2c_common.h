@@ -111,6 +111,7 @@ enum W2COption {
     W2C_OPT_S2WREG_FORM,      // stride-2 block fronts (conv_s2wreg.inl): 1 (default) .. 4: that kernel form wherever it fits | 0 = not offered (ring kernel)
     W2C_OPT_WREG_SMALL,       // 0 (default) = never | n: wreg launches with fewer 128-px x 64-ch tiles than n take the 32-channels-per-wave form (96)
     W2C_OPT_S2REGH,           // 1 (default) | 0: the first stride-2 block front (64 -> 128) on the persistent weights-stationary kernel (conv_s2regh.inl)
+    W2C_OPT_UPS_LDS_KB,       // 0 (default) | n <= 64: LDS request of the x32 upsample's workgroups padded to n KB (A/B: fewer resident workgroups)
     W2C_OPT_COUNT
 };
 int w2c_option(int id);
