@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH", "W2C_UPS_LDS_KB"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH", "W2C_UPS_LDS_KB", "W2C_LDS_PAD_KB"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 0, 1, 0};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 0, 1, 0, 0};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -1911,7 +1911,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     (void)hipGetDevice(&dev);
     if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     dim3 grid(a.ntm * a.ntn, groups);
@@ -1921,7 +1921,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20) && 2 * wbytes >= xbytes)) && groups == 2 && !(a.ntm & 1) &&
               !(a.ntn & 1) && (a.ntm * a.ntn) % 4 == 0;
     if (a.xcd2d) grid = dim3(a.ntm * a.ntn * 2, 1);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), w2c_padded_lds(lds), s, a);
     return w2c_launch_status();
 }
 

@@ -46,6 +46,8 @@ _FP8_SERIAL = bool(os.environ.get('W2C_FP8_SERIAL'))
 _NO_TAIL_OVERLAP = bool(os.environ.get('W2C_NO_TAIL_OVERLAP'))
 _HEAD_MFMA = os.environ.get('W2C_HEAD_MFMA', '1') != '0'   # fc.0 of the heads on the f32 matrix pipe (split-K partials)
 _GATE_U = os.environ.get('W2C_GATE_U', '1') != '0'         # the decoder's value-map conv waits for the policy chain's conv2
+_VALUE_LDS_KB = int(os.environ.get('W2C_VALUE_LDS_KB', '0'))   # A/B: LDS request of the value chain's conv launches (84: never two of them on one CU)
+_POLICY_LDS_KB = int(os.environ.get('W2C_POLICY_LDS_KB', '0'))  # (control: the same for the policy chain)
 _GRAPH_IO = os.environ.get('W2C_GRAPH_IO', '1') != '0'     # the stem and the upsample inside the captured graph (pointer slots)
 
 
@@ -330,6 +332,17 @@ class TrunkPlan:
         lag_ev = None
 
         def chain(g):
+            pad = _VALUE_LDS_KB if g == 0 else _POLICY_LDS_KB
+            if not pad:
+                return chain_body(g)
+            from . import _native
+            old_pad = _native.set_option("W2C_LDS_PAD_KB", pad)
+            try:
+                return chain_body(g)
+            finally:
+                _native.set_option("W2C_LDS_PAD_KB", old_pad)
+
+        def chain_body(g):
             nonlocal lag_ev
             _stamp(1 + g)
             q, off = p, g * cin0
