@@ -2547,7 +2547,15 @@ extern "C" int w2c_debug_conv_timeline(void* buf) {
 
 // Debug: one-thread kernel that writes the 100 MHz wall clock to slot[0] -- a time stamp in stream order (tools/chain_stamps.py:
 // when does each launch chain of a captured forward start?).
-__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+// slot[32] = the shader-clock counter at the same instant: (d slot[32] / d slot[0]) x 100 MHz = the clock the chip held between two stamps
+// (the counter is per XCD: the XCC id rides in the top 4 bits, a reader compares stamps of the same XCD only)
+__global__ void stamp_kernel(unsigned long long* slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;       // hwreg(HW_REG_XCC_ID, 0, 4)
+    slot[0] = wall_clock64();
+    slot[32] = (xcc << 60) | ((unsigned long long)clock64() & ((1ull << 60) - 1));
+#endif
+}
 extern "C" int w2c_debug_stamp(void* slot, w2c_stream_t stream) {
     w2c_clear_error();
     stamp_kernel<<<1, 1, 0, reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<unsigned long long*>(slot));

@@ -22,7 +22,7 @@ engine.STAMPS = torch.zeros(64, dtype=torch.int64, device="cuda:0")
 for _ in range(6):
     m(x, training=False, MO_flag=True, inference="softmax")
 torch.cuda.synchronize()
-for rep in range(3):
+for rep in range(8):
     for _ in range(4):                       # back to back: the host is ahead of the device, as in bench.py
         m(x, training=False, MO_flag=True, inference="softmax")
     torch.cuda.synchronize()
@@ -33,3 +33,18 @@ for rep in range(3):
         t[2] - t0, " ".join("%.0f" % (v - t0) for v in t[16:22]), t[4] - t0, t[5] - t0), flush=True)
     print("     policy convs end +%.1f | heads end +%.1f | join +%.1f | graph+fuse end +%.1f | decoder convs end +%.1f us" % (
         t[6] - t0, t[7] - t0, t[5] - t0, t[24] - t0, t[25] - t0), flush=True)
+    # shader clock held between consecutive stamps of the policy chain (w2c_debug_stamp writes clock64() 32 slots behind the wall clock)
+    raw = engine.STAMPS.cpu().numpy().astype("float64")
+    iraw = engine.STAMPS.cpu().numpy().astype("uint64")
+    xcc = (iraw >> 60).astype("int64")
+    clk = (iraw & ((1 << 60) - 1)).astype("float64")
+    seq = [("fork", 0), ("head", 2)] + [("blk%d" % i, 16 + i) for i in range(6)] + [("trunk end", 4), ("policy convs", 6), ("heads", 7), ("join", 5),
+                                                                                      ("graph+fuse", 24), ("decoder", 25)]
+    out = []
+    for (na, a), (nb, b) in zip(seq[:-1], seq[1:]):
+        dw, dc = raw[b] - raw[a], clk[b + 32] - clk[a + 32]
+        mhz = dc / dw * 100.0 if dw > 0 else 0.0
+        # the counter is per XCD and the stamp kernels land on any of them: only a pair from one XCD gives a clock (the XCC id in the top
+        # bits is compared too, but the plausibility window is what filters in practice)
+        out.append("%s %s" % (nb, ("%.0f" % mhz) if (xcc[a + 32] == xcc[b + 32] and 500.0 < mhz < 3000.0) else "-"))
+    print("     MHz held up to (pairs of stamps from one XCD only): " + " | ".join(out), flush=True)
