@@ -747,6 +747,19 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool writer = blockIdx.x == 0;
     if (tid == 0) *cnt = 0;
+    // small graphs (N <= 8): the keys' 16 bytes of this thread's FIRST item do not depend on the graph -- they are requested here, so that
+    // their memory round trip runs under the graph column's (loads of q / T, dot products, softmax) instead of behind it.  Every key is
+    // loaded (the thresholded modes' unused maps are valid memory: zeros or the gathered map); which ones are USED is still decided by the
+    // coefficients below: same fmaf sequence, same bits.
+    const int CGp = C >> 2;
+    const int id0 = blockIdx.x * 256 + threadIdx.x;
+    f32x4_t uk0[8];
+    if (N <= 8 && id0 < hw * CGp) {
+        const int px = id0 / CGp, cg = id0 - px * CGp;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            uk0[k] = k < N ? *reinterpret_cast<const f32x4_t*>(u + ((size_t)(k * B + b) * hw + px) * ucs + cg * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
     int local_nnz = 0;
     for (int ql = wave; ql < q_n; ql += 4) {
@@ -784,12 +797,17 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
         if (N <= 8) {
             // small graphs (cfg 2: 5 agents): all keys' 16 bytes in flight together; a key no query uses is not loaded (wave-uniform)
             f32x4_t uk[8];
+            if (id == id0) {                                      // the prefetched item
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                bool used = false;
-                if (k < N)
-                    for (int ql = 0; ql < q_n; ++ql) used |= cs[k * q_n + ql] != 0.f;
-                uk[k] = used ? *reinterpret_cast<const f32x4_t*>(u + ((size_t)(k * B + b) * hw + px) * ucs + cg * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 8; ++k) uk[k] = uk0[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bool used = false;
+                    if (k < N)
+                        for (int ql = 0; ql < q_n; ++ql) used |= cs[k * q_n + ql] != 0.f;
+                    uk[k] = used ? *reinterpret_cast<const f32x4_t*>(u + ((size_t)(k * B + b) * hw + px) * ucs + cg * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
             }
             for (int ql = 0; ql < q_n; ++ql) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
