@@ -285,6 +285,25 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
     float* s_part = s_h1 + H1;                             // [1024]
     const HeadTailSet& s = blockIdx.y == 0 ? a : b;
     const int m = blockIdx.x, tid = threadIdx.x;
+    // The weights of stages 1 and 2 do not depend on the activations: this thread's 32 + 16 values are requested up front, so that their
+    // memory round trips run under stage 0's instead of two more behind it (three dependent round trips -> one; the dispatched shape:
+    // K1 / (1024 / H1) == 32).  Same values, same fmaf order.
+    const int P1 = 1024 / H1, j1 = tid % H1, p1 = tid / H1;
+    const int kn1 = (K1 - p1 + P1 - 1) / P1;
+    const bool pre = kn1 == 32;
+    float wv1[32], wv2[16];
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) wv1[u] = s.w1t[(size_t)(p1 + u * P1) * H1 + j1];
+    }
+    {
+        const int o = tid & 63, p = tid >> 6;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = p + u * 16;
+            wv2[u] = (o < s.O && k < H1) ? s.w2t[(size_t)k * s.O + o] : 0.f;
+        }
+    }
     {   // stage 0: h0[k] = relu(sum_p part_p[m][col_off + k] + b0): thread = (k, group of n_part / G consecutive partials)
         const int G = 1024 / K1, per = n_part / G;
         const int k = tid % K1, g = tid / K1;
@@ -313,6 +332,11 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
         const int kn = (K1 - p + P - 1) / P;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         int i = 0;
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc[u & 3] = fmaf(wv1[u], s_h0[p + u * P], acc[u & 3]);
+            i = 32;
+        }
         for (; i + 32 <= kn; i += 32) {
             float wv[32];
 #pragma unroll
@@ -334,19 +358,10 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
         const int o = tid & 63, p = tid >> 6;              // 16 partitions
         float acc = 0.f;
         if (o < s.O) {
-            float wv[16];
-            int n = 0;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int k = p + u * 16;
-                wv[u] = k < H1 ? s.w2t[(size_t)k * s.O + o] : 0.f;
-                n = u;
-            }
-            (void)n;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = p + u * 16;
-                if (k < H1) acc = fmaf(wv[u], s_h1[k], acc);
+                if (k < H1) acc = fmaf(wv2[u], s_h1[k], acc);
             }
         }
         s_part[tid] = acc;
