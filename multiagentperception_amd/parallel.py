@@ -100,6 +100,24 @@ def sparse_exchange(v_local, need, B, N, group=None):
     return v_all, len(flat_recv), (world - 1) * n_loc * B
 
 
+_WATCHDOG_DRAIN_S = float(os.environ.get("W2C_WATCHDOG_DRAIN_S", "0.35"))
+
+
+def _drain_watchdog(group=None):
+    """Before a capture that has RCCL collectives inside it: let ProcessGroupNCCL's watchdog thread retire the EAGER collectives issued
+    just before (the warm-up runs, the audition's all-reduce).  The watchdog polls its list every 100 ms and asks every listed work's end
+    event whether it has completed; those events were recorded on the process group's internal stream, and while that stream is part of a
+    capture HIP answers the query with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream") --
+    the watchdog rethrows and the process aborts.  Works issued DURING capture are never listed, so the hazard is exactly the eager works
+    that are still listed when a capture window opens: a poll that lands inside one of the audition's four windows (seen as an
+    intermittent abort of `bench.py --force-sharded` once the audition had widened the exposure from one capture to four).  There is no
+    API to flush the list; every listed work has completed (the caller has synchronised), so three poll periods empty it.  One-time cost
+    per captured shape."""
+    if _WATCHDOG_DRAIN_S > 0 and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        import time
+        time.sleep(_WATCHDOG_DRAIN_S)
+
+
 def shard_agents(agent_num, world, rank):
     if agent_num % world != 0:
         raise ValueError("agent_num %d is not divisible by world size %d" % (agent_num, world))
@@ -323,6 +341,7 @@ class AgentParallelForward:
                     whole()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
+            _drain_watchdog(self.group)
             # audition of the instantiation (engine.CommEngine._audition: a bad assignment of the graph's branches to hardware queues
             # replays 2-3x slower for the graph's whole life, and with N ranks one such rank slows every step of all of them).  The
             # collectives are inside the graph, so every rank must keep the SAME candidate: the candidates' times are MAX-reduced over
@@ -349,6 +368,8 @@ class AgentParallelForward:
                 if self.world > 1:
                     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 t = float(t.item())
+                if self.world > 1 and i + 1 < max(1, _GRAPH_AUDITION):
+                    _drain_watchdog(self.group)              # (the eager all-reduce above is in the watchdog's list; the next capture follows)
                 times.append(round(t, 4))
                 if best is None or t < best[0]:
                     best = (t, cand)
