@@ -367,3 +367,68 @@ def test_decoder_conv0_commutes_with_the_fusion(who):
         if who:
             rhs = rhs + F.conv2d(V[:, q], W[:, C:], None, padding=1)
         assert float((lhs - F.relu(rhs)).abs().max()) < 1e-10
+
+
+# ---- csrc/conv_s2regh.inl (layer2.0's front): the index arithmetic of the phase-image patch, restated in numpy -------------------------------
+_S2_TAP_ORDER = [(0, 0), (0, 2), (2, 0), (2, 2), (0, 1), (2, 1), (1, 0), (1, 2), (1, 1)]           # s2_tap order (ky, kx)
+_S2R_PHASES = [  # (py, px, first flat pixel, pitch, rows)
+    (1, 1, 0, 9, 9), (1, 0, 88, 8, 9), (0, 1, 160, 9, 8), (0, 0, 232, 8, 8)]
+
+
+def _s2r_phase_of(ky, kx):
+    return {(1, 1): 0, (1, 0): 1, (0, 1): 2, (0, 0): 3}[(int(ky != 1), int(kx != 1))]
+
+
+def test_s2_front_phase_patch_addressing_equals_a_stride2_conv():
+    """conv_s2regh.inl stages the 17 x 17 input patch of an 8 x 8 output tile as four phase images (flat pixels 0..295: 9x9 | 9x8 | 8x9 | 8x8
+    blocks, exact pitches) and reads tap (ky, kx) of output (oy, ox) at block (oy + [ky == 2], ox + [kx == 2]) of phase ([ky != 1], [kx != 1]).
+    The same arithmetic here, for a border tile (top / left halo = zeros) and an interior one, against a direct 3x3 / stride-2 / pad-1 conv."""
+    rng = np.random.default_rng(5)
+    H = W = 32
+    x = rng.standard_normal((H, W)).astype(np.float64)
+    w = rng.standard_normal((3, 3)).astype(np.float64)
+    xp = np.pad(x, 1)
+    for oy0, ox0 in ((0, 0), (8, 8), (0, 8)):
+        patch = np.zeros(296)
+        for py, px, base, pitch, rows in _S2R_PHASES:
+            for br in range(rows):
+                for bc in range(pitch):
+                    iy, ix = 2 * oy0 - 1 + 2 * br + (1 - py), 2 * ox0 - 1 + 2 * bc + (1 - px)
+                    assert iy < H and ix < W                                   # (only the top / left halo ever leaves the image)
+                    patch[base + br * pitch + bc] = x[iy, ix] if (iy >= 0 and ix >= 0) else 0.0
+        for r in range(8):
+            for c in range(8):
+                acc = 0.0
+                for ky, kx in _S2_TAP_ORDER:
+                    py, px, base, pitch, rows = _S2R_PHASES[_s2r_phase_of(ky, kx)]
+                    acc += w[ky, kx] * patch[base + (r + (ky == 2)) * pitch + (c + (kx == 2))]
+                oy, ox = oy0 + r, ox0 + c
+                want = sum(w[ky, kx] * xp[2 * oy + ky, 2 * ox + kx] for ky in range(3) for kx in range(3))
+                assert abs(acc - want) < 1e-12
+
+
+def test_s2_front_fragment_reads_are_bank_conflict_free():
+    """the swizzle of conv_s2regh.inl: chunk c of the pixel at block (br, bc) sits at 16-byte slot c ^ (((bc >> 1) & 3) | ((br & 1) << 2)); a
+    quarter-wave of a fragment read (lanes = 2 block rows x 8 columns, one K slice and half) must cover the 16 bank groups of 16 bytes once"""
+    for ky, kx in _S2_TAP_ORDER:
+        py, px, base, pitch, rows = _S2R_PHASES[_s2r_phase_of(ky, kx)]
+        for pt in range(2):
+            for kc in range(4):
+                for lhi in range(2):
+                    for half in range(2):                                      # lanes l31 = 0..15 | 16..31: block rows (0, 1) | (2, 3)
+                        groups = set()
+                        for l in range(16):
+                            r, c = 2 * half + l // 8, l % 8
+                            br, bc = 4 * pt + r + (ky == 2), c + (kx == 2)
+                            slot = ((2 * kc) | lhi) ^ (((bc >> 1) & 3) | ((br & 1) << 2))
+                            addr = (base + br * pitch + bc) * 128 + slot * 16
+                            groups.add((addr // 16) % 16)
+                        assert len(groups) == 16, (ky, kx, pt, kc, lhi, half)
+
+
+def test_watchdog_drain_is_a_no_op_without_an_rccl_group():
+    import time
+    from multiagentperception_amd import parallel
+    t0 = time.perf_counter()
+    parallel._drain_watchdog()
+    assert time.perf_counter() - t0 < 0.1
