@@ -317,6 +317,11 @@ int w2c_debug_conv_timeline(void* buf);
 int w2c_debug_conv_span(void* slot);
 /* Debug: enqueue a one-thread kernel that writes the 100 MHz wall clock to *slot (u64): a time stamp in stream order. */
 int w2c_debug_stamp(void* slot, w2c_stream_t stream);
+/* Debug (round 5): install handlers for SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL that write the NATIVE call stack of the faulting
+   thread to stderr (backtrace_symbols_fd: async-signal-safe) and then chain to whatever handler was installed before (Python's
+   faulthandler under pytest), so that a crash inside a runtime library is named by its frame, not only by the Python line above it.
+   tests/conftest.py calls it once; the product path never does.  Returns W2C_OK. */
+int w2c_debug_install_crash_backtrace(void);
 
 /* ---- K5: Linear (+ReLU) for the key/query heads (agent.py:150-159,167-178).
  * x : [M, K] bf16 (x_is_bf16=1, row stride x_stride elements) or f32
@@ -391,7 +396,7 @@ int w2c_comm_graph_fuse(const float* query, const float* tproj, int B, int N, in
 
 
 /* ---- K5, round 4: fc.0 of the key / query heads (agent.py:150-151) on the f32 matrix pipe (v_mfma_f32_32x32x2_f32: exact f32).
- * x     : bf16 [M <= 64][x_stride] policy map rows (K = 4096 features each)
+ * x     : bf16 [M][x_stride] policy map rows (K = 4096 features each)
  * wfrag : f32 fc.0 weights of all heads stacked along O ([O][K]), FRAGMENT-PACKED:
  *         wfrag[((o / 32) * (K / 8) + q) * 256 + (half * 32 + o % 32) * 4 + e] = W[o][8 q + 4 half + e]
  * part  : f32 [ksplit][M][O] split-K partial sums (no bias, no ReLU); K % (256 ksplit) == 0, O % 32 == 0

@@ -36,6 +36,7 @@ SIGNATURES = {
     "w2c_conv3x3_wreg_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _vp],
     "w2c_debug_conv_timeline": [_vp],
     "w2c_debug_stamp": [_vp, _vp],
+    "w2c_debug_install_crash_backtrace": [],
     "w2c_debug_conv_span": [_vp],
     "w2c_conv_igemm_fp8": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _vp, _i, _f,
                            _vp, _i, _vp],

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
 //   the 4 waves' partial tiles meet in LDS, are added in wave order and stored as ONE partial per (K-split, row, column):
 //   part[ks][m][o].  The tail kernel adds the KS partials in order (+ bias, ReLU).  Deterministic; independent of M (an output's
 //   sum order is fixed by (ks, wave, q, e)), so a rank's shard rounds like the unsharded batch.
-template <int RB>                                          // 32-row blocks of x (M <= 32 RB)
+template <int RB>                                          // 32-row blocks of x per workgroup (grid.z workgroups cover M rows)
 __global__ __launch_bounds__(256) void head_fc0_mfma_kernel(const uint16_t* __restrict__ x, int x_stride, int M, int K,
                                                             const float* __restrict__ wf, int O, float* __restrict__ part) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void head_fc0_mfma_kernel(const uint16_t* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ot = blockIdx.x, ks = blockIdx.y, KS = gridDim.y;
+    const int mb = blockIdx.z * (32 * RB);                   // first row of this workgroup's row block (any M: grid.z row blocks)
     const int kw = K / KS / 4;                               // K slice of a wave (multiple of 8)
     const int k0 = ks * (K / KS) + wave * kw;
     const int nq = kw >> 3;
@@ -401,7 +402,8 @@ __global__ __launch_bounds__(256) void head_fc0_mfma_kernel(const uint16_t* __re
     const uint16_t* xp[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        const int m = rb * 32 + l31 < M ? rb * 32 + l31 : M - 1;          // clamp: rows past M are computed and dropped
+        const int mr = mb + rb * 32 + l31;
+        const int m = mr < M ? mr : M - 1;                                // clamp: rows past M are computed and dropped
         xp[rb] = x + (size_t)m * x_stride + k0 + 4 * lhi;
     }
     f32x16_t acc[RB];
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void head_fc0_mfma_kernel(const uint16_t* __re
     for (int i = tid; i < RB * 16 * 64; i += 256) {
         const int ln = i & 63, r = (i >> 6) & 15, rb = i >> 10;
         const float v = ((red[0][rb][r][ln] + red[1][rb][r][ln]) + red[2][rb][r][ln]) + red[3][rb][r][ln];
-        const int m = rb * 32 + (ln & 31), o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int m = mb + rb * 32 + (ln & 31), o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
         if (m < M) part[((size_t)ks * M + m) * O + o] = v;
     }
 #endif
@@ -923,12 +925,12 @@ extern "C" int w2c_head_tail2_f32(const float* h0, int h0_stride, int M, int K1,
 extern "C" int w2c_head_fc0_mfma_f32(const uint16_t* x, int x_stride, int M, int K, const float* wfrag, int O, int ksplit,
                                      float* part, w2c_stream_t stream) {
     w2c_clear_error();
-    if (!x || !wfrag || !part || M <= 0 || M > 64 || K <= 0 || O <= 0 || (O % 32) != 0 || ksplit <= 0) return W2C_E_ARG;
+    if (!x || !wfrag || !part || M <= 0 || K <= 0 || O <= 0 || (O % 32) != 0 || ksplit <= 0) return W2C_E_ARG;
     if ((K % (ksplit * 256)) != 0 || (x_stride % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(wfrag) & 15))
         return W2C_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M <= 32) hipLaunchKernelGGL((head_fc0_mfma_kernel<1>), dim3(O / 32, ksplit), dim3(256), 0, s, x, x_stride, M, K, wfrag, O, part);
-    else hipLaunchKernelGGL((head_fc0_mfma_kernel<2>), dim3(O / 32, ksplit), dim3(256), 0, s, x, x_stride, M, K, wfrag, O, part);
+    else hipLaunchKernelGGL((head_fc0_mfma_kernel<2>), dim3(O / 32, ksplit, (M + 63) / 64), dim3(256), 0, s, x, x_stride, M, K, wfrag, O, part);
     return w2c_launch_status();
 }
 

@@ -585,6 +585,45 @@ extern "C" int w2c_copy_to_slot(const void* src, long long nbytes, void* dst, w2
     return w2c_launch_status();
 }
 
+// ---- debug: native backtrace on fatal signals (include/w2c_hip.h) ----
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+struct sigaction g_prev_sa[65];
+void crash_backtrace_handler(int sig, siginfo_t* info, void* uc) {
+    void* frames[96];
+    const int n = backtrace(frames, 96);
+    static const char head[] = "\n==== libw2c_hip: native backtrace of the faulting thread ====\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    static const char tail[] = "==== end of native backtrace ====\n";
+    (void)!write(2, tail, sizeof(tail) - 1);
+    const struct sigaction& prev = g_prev_sa[sig];
+    if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction) {
+        prev.sa_sigaction(sig, info, uc);
+    } else if (!(prev.sa_flags & SA_SIGINFO) && prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN) {
+        prev.sa_handler(sig);
+    }
+    signal(sig, SIG_DFL);                                // (a chained handler that returns: die with the default action)
+    raise(sig);
+}
+}  // namespace
+extern "C" int w2c_debug_install_crash_backtrace(void) {
+    void* warm[4];
+    (void)backtrace(warm, 4);                            // loads libgcc's unwinder now, outside any signal handler
+    static const int sigs[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL};
+    for (int sig : sigs) {
+        struct sigaction sa;
+        sa.sa_sigaction = crash_backtrace_handler;
+        sigemptyset(&sa.sa_mask);
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+        struct sigaction old;
+        if (sigaction(sig, &sa, &old) == 0 && old.sa_sigaction != crash_backtrace_handler) g_prev_sa[sig] = old;
+    }
+    return W2C_OK;
+}
+
 extern "C" int w2c_version(void) { return 1; }
 
 extern "C" const char* w2c_last_error_string(void) { return w2c_errbuf(); }

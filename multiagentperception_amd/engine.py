@@ -543,7 +543,7 @@ class HeadPlan:
         self.w0 = w0.to(dev)
         self.b0 = torch.cat(b0s).contiguous().to(dev)
         self.n_feat = n_feat
-        # fragment-ordered copy for the f32-MFMA form of fc.0 (ops.head_fc0_mfma; two heads of equal width, <= 64 rows)
+        # fragment-ordered copy for the f32-MFMA form of fc.0 (ops.head_fc0_mfma; two heads of equal width; any row count: grid.z row blocks)
         self.w0frag = ops.pack_fc0_frag(w0).to(dev) if (_HEAD_MFMA and w0.shape[0] % 32 == 0 and w0.shape[1] % 8 == 0) else None
 
     def run(self, qk_map, outs=None):
@@ -884,8 +884,7 @@ class CommEngine:
                 whole()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with ops.capture() as graph:
             pack = whole()
         return graph, slots, pack
 
@@ -907,8 +906,7 @@ class CommEngine:
                 middle(s0)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with ops.capture() as graph:
             low, prob, action, nnz = middle(s0)
             pack = self._last_pack
         return s0, graph, low, pack
@@ -994,8 +992,7 @@ class SRMSEngine:
                     self._forward(xs, mode, out=outs)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with ops.capture() as graph:
                 res = self._forward(xs, mode, out=outs)
             ent = graphs[key] = (graph, xs, slots, res[1:])
         graph, xs, slots, small = ent
@@ -1018,9 +1015,11 @@ class SRMSEngine:
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     parts.append(t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1))
+            capturing = torch.cuda.is_current_stream_capturing()
             for i in range(len(self.trunks5)):
                 main.wait_stream(self.trunk._side_stream(x.device, 2 + i))
-                parts[i].record_stream(main)
+                if not capturing:                   # eager: the block was allocated on the side stream and is consumed on main.  Inside a
+                    parts[i].record_stream(main)    # capture the graph's own edges order producer, consumer and any reuse of the block
             vcs_src = torch.cat(parts, 0)
             pol_off = 0
         elif self.trunk0 is not None:

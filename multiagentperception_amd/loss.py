@@ -29,13 +29,26 @@ _bad_labels = {}            # device -> [accumulated count tensor, calls since t
 
 
 _CHECK_LABELS_EVERY_CALL = __import__("os").environ.get("W2C_CHECK_LABELS") == "1"      # read once; tests flip the module attribute
+_label_check_group = None   # None: the check is LOCAL to the rank (default).  (group,): the flag is MAX-all-reduced over `group` first
+
+
+def set_label_check_collective(enabled, group=None):
+    """Opt in: make the periodic out-of-range-label check a collective over `group` (None = the world), so that every rank
+    raises together.  Only for loops in which EVERY rank of the group calls the loss the same number of times -- a rank-0-only
+    validation pass or an uneven last batch would leave the ranks in different collectives.  Off by default: the loss never
+    communicates unless asked to.  Returns the previous setting."""
+    global _label_check_group
+    prev = _label_check_group
+    _label_check_group = (group,) if enabled else None
+    return prev
 
 
 def _note_bad_labels(out3):
     """Off the hot path: the count is added on the device (no sync), and read back on the first call, then every
-    _LABEL_CHECK_EVERY calls.  The error names the range of calls it covers; in a distributed run the flag is all-reduced (MAX)
-    first, so every rank raises together instead of one rank leaving the others in the next collective.  Skipped while a HIP graph
-    is being captured (a captured training step checks labels through W2C_CHECK_LABELS runs outside capture)."""
+    _LABEL_CHECK_EVERY calls.  The error names the range of calls it covers.  The check is local to the rank: the loss issues no
+    collective unless set_label_check_collective(True, group) asked for one (then the flag is MAX-all-reduced over that group first, so
+    every rank raises together).  Skipped while a HIP graph is being captured (a captured training step checks labels through
+    W2C_CHECK_LABELS runs outside capture)."""
     if torch.cuda.is_current_stream_capturing():
         return
     dev = out3.device
@@ -49,9 +62,10 @@ def _note_bad_labels(out3):
         first, last = st[3], st[2]
         st[1], st[3] = 0, st[2] + 1
         flag = st[0].clone()
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if _label_check_group is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=_label_check_group[0])
         bad_any, bad = int(flag.item()), int(st[0].item())
         st[0].zero_()
         if bad_any:

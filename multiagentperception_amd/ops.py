@@ -67,6 +67,47 @@ class SlotRef:
         return True
 
 
+class capture:
+    """`with ops.capture() as graph:` -- capture the launches of the block into a fresh torch.cuda.CUDAGraph (thread-local error mode) with
+    Python's cyclic garbage collector held off for the length of the window.
+
+    Why (round 5, the crash of GPUTEST_r04; tools/r05/gc_in_capture.py reproduces it in 12 lines): objects kept alive only by a reference
+    cycle -- a model + engine + its graphs inside a pytest.raises traceback, a closure -- are freed whenever the cyclic collector happens to
+    run, i.e. at an arbitrary allocation.  If that is inside a capture window and the garbage holds an OLD CUDAGraph, its destructor
+    (at::cuda::CUDAGraph::~CUDAGraph: hipGraphExecDestroy, pool release, and on ROCm a hipDeviceSynchronize) runs in the middle of the
+    capture: the runtime refuses the synchronize while a stream is capturing, the check throws inside a destructor and the process dies
+    (native frame: at::cuda::CUDAGraph::~CUDAGraph -> c10::hip::c10_hip_check_implementation -> std::terminate;
+    profiles/r05_capture_crash.txt).  PyTorch used to run gc.collect() before every capture; 2.10 does so only on request.  So: collect
+    BEFORE the window (old graphs die outside it), disable the collector INSIDE it (nothing is finalised between begin and end capture),
+    restore it after.  Every capture of this package goes through here."""
+
+    def __init__(self, graph=None, thread_local=True):
+        self.graph = graph if graph is not None else torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self.graph, capture_error_mode="thread_local") if thread_local else torch.cuda.graph(self.graph)
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        self._gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._ctx.__enter__()
+        except BaseException:
+            if self._gc_was_on:
+                gc.enable()
+            raise
+        return self.graph
+
+    def __exit__(self, et, ev, tb):
+        import gc
+        try:
+            return self._ctx.__exit__(et, ev, tb)
+        finally:
+            if self._gc_was_on:
+                gc.enable()
+
+
 def set_slots(slots, tensors):
     """w2c_set_slots: slots[i] = address of tensors[i] (None -> 0), in stream order on the current stream."""
     import ctypes
@@ -978,7 +1019,8 @@ HEAD_FC0_KSPLIT = 16
 
 
 def head_fc0_supported(M, K, O, ksplit=HEAD_FC0_KSPLIT):
-    return M <= 64 and O % 32 == 0 and K % (ksplit * 256) == 0
+    # geometry only (never the row count M): a rank's shard and the unsharded batch must take the same kernel
+    return O % 32 == 0 and K % (ksplit * 256) == 0
 
 
 def head_fc0_mfma(x, x_stride, M, K, wfrag, O, ksplit=HEAD_FC0_KSPLIT, part=None):

@@ -100,22 +100,81 @@ def sparse_exchange(v_local, need, B, N, group=None):
     return v_all, len(flat_recv), (world - 1) * n_loc * B
 
 
-_WATCHDOG_DRAIN_S = float(os.environ.get("W2C_WATCHDOG_DRAIN_S", "0.35"))
+# ProcessGroupNCCL's flight recorder is how _watchdog_idle() SEES the watchdog's list (see there).  Its ring buffer must exist when the
+# process group is created; recent PyTorch enables it by default, older builds read this variable.
+os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
+_WATCHDOG_IDLE_TIMEOUT_S = float(os.environ.get("W2C_WATCHDOG_IDLE_TIMEOUT_S", "20"))
 
 
-def _drain_watchdog(group=None):
-    """Before a capture that has RCCL collectives inside it: let ProcessGroupNCCL's watchdog thread retire the EAGER collectives issued
-    just before (the warm-up runs, the audition's all-reduce).  The watchdog polls its list every 100 ms and asks every listed work's end
-    event whether it has completed; those events were recorded on the process group's internal stream, and while that stream is part of a
-    capture HIP answers the query with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream") --
-    the watchdog rethrows and the process aborts.  Works issued DURING capture are never listed, so the hazard is exactly the eager works
-    that are still listed when a capture window opens: a poll that lands inside one of the audition's four windows (seen as an
-    intermittent abort of `bench.py --force-sharded` once the audition had widened the exposure from one capture to four).  There is no
-    API to flush the list; every listed work has completed (the caller has synchronised), so three poll periods empty it.  One-time cost
-    per captured shape."""
-    if _WATCHDOG_DRAIN_S > 0 and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
-        import time
-        time.sleep(_WATCHDOG_DRAIN_S)
+def _fr_entries(only_active):
+    import pickle
+    from torch._C._distributed_c10d import _dump_nccl_trace
+    d = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=only_active))
+    return d.get("entries", []) if isinstance(d, dict) else []
+
+
+_captured_ids = set()        # flight-recorder ids of collectives issued INSIDE capture windows: never listed by the watchdog, never retired
+
+
+def _fr_max_id():
+    ents = _fr_entries(False)
+    return max((int(e.get("record_id", -1)) for e in ents), default=-1)
+
+
+class _collectives_captured:
+    """wraps a capture window that has collectives inside: their flight-recorder entries (one per collective, recorded whether or not the
+    work is handed to the watchdog) are remembered, so that _watchdog_idle() does not wait for them -- nobody will ever retire them."""
+
+    def __enter__(self):
+        try:
+            self.lo = _fr_max_id()
+        except Exception:
+            self.lo = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.lo is not None:
+            try:
+                _captured_ids.update(range(self.lo + 1, _fr_max_id() + 1))
+            except Exception:
+                pass
+        return False
+
+
+def _watchdog_idle(group=None, timeout_s=None):
+    """Before a capture that has RCCL collectives inside it: wait until ProcessGroupNCCL's watchdog thread has RETIRED every eager
+    collective issued so far (the warm-up runs, an agreement all-reduce).  Why: the watchdog polls its list of works and asks every listed
+    work's end event whether it has completed; those events were recorded on the process group's internal stream, and while that stream
+    is part of a capture HIP answers the query with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a
+    capturing stream") -- the watchdog rethrows and the process aborts.  Works issued DURING capture are never listed, so the hazard is
+    exactly the eager works still listed when a capture window opens.
+    Round 4 slept three poll periods and hoped.  Round 5 observes: the process group's flight recorder keeps one entry per collective
+    and the watchdog sets its `retired` flag at the moment it erases the work from its list (tools/r05/fr_probe.py on the GPU box: state
+    'completed' first, `retired` ~80 ms later); this polls the recorder until every entry of an eager collective is retired (the caller
+    has synchronised the device, so every listed work HAS completed and the next watchdog pass retires it).  If the recorder cannot show
+    that (disabled: no entries at all although collectives ran; or still un-retired after the timeout) this raises RuntimeError -- the
+    caller then takes the 3-segment form, whose collectives are eager and never captured: no proof, no capture.
+    -> seconds waited."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
+        return 0.0
+    import time
+    t0 = time.monotonic()
+    limit = _WATCHDOG_IDLE_TIMEOUT_S if timeout_s is None else timeout_s
+    try:
+        while True:
+            ents = _fr_entries(False)
+            if not ents:
+                raise RuntimeError("flight recorder holds no entries")
+            busy = [e for e in ents if not e.get("retired", False) and int(e.get("record_id", -1)) not in _captured_ids]
+            if not busy:
+                return time.monotonic() - t0
+            if time.monotonic() - t0 > limit:
+                raise RuntimeError("%d eager collectives still listed after %.0f s" % (len(busy), limit))
+            time.sleep(0.005)
+    except RuntimeError as e:
+        raise RuntimeError("cannot prove ProcessGroupNCCL's watchdog list empty (%s): not capturing collectives" % (e,))
+    except Exception as e:                                 # recorder API missing / changed
+        raise RuntimeError("cannot prove ProcessGroupNCCL's watchdog list empty (flight recorder unavailable: %r)" % (e,))
 
 
 def shard_agents(agent_num, world, rank):
@@ -179,8 +238,8 @@ class _ShardState:
                     fn()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            from . import ops
+            with ops.capture() as g:
                 res = fn()
             self.graphs[name] = (g, res)
             g = self.graphs[name]
@@ -308,22 +367,36 @@ class AgentParallelForward:
             outs = ops.SlotRef(slots, 1, out)
             rows = n_loc * B
 
+            pol_stream = eng.trunk._side_stream(dev)        # the policy chain's stream (engine.TrunkPlan.after_stem)
+
             def whole():
                 eng.trunk.stem(xs, n_loc, out=st.s0)
-                works = []
+                works, done = [], {}
+
+                def gather_k():
+                    works.append(_gather_inplace(st.k_all, self.rank, rows, self.group))
+                    done["k"] = True
 
                 def value_tail(v):
+                    # U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K gather
+                    # (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel under
+                    # the policy tail.  The K gather is issued from the policy chain's stream, behind the heads.
                     u = eng.value_maps(v, out=st.v_slot)
                     works.append(_gather_inplace(st.v_all, self.rank, rows, self.group))
+                    if done.get("heads"):
+                        with torch.cuda.stream(pol_stream):
+                            gather_k()
                     return u
 
                 def policy_tail(pol):
                     y = eng.policy_convs(pol, ch_off=0, gate=True)
                     eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
-                    works.append(_gather_inplace(st.k_all, self.rank, rows, self.group))
+                    done["heads"] = True
                     return y
 
                 eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
+                if not done.get("k"):
+                    gather_k()                               # (an after_stem form that ran the value tail before the policy tail)
                 for wk in works:
                     exchange_wait(wk)
                 pack2 = ops.SlotRef(slots, 2, ops.graph_outputs(dev, B, N, n_loc)[0])
@@ -332,49 +405,58 @@ class AgentParallelForward:
                 ops.upsample_bilinear32(low, eng.n_classes, out=outs)
                 return pack
 
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                pack0 = ops.graph_outputs(dev, B, N, n_loc)[0]
-                ops.set_slots(slots, [x, out, pack0])
-                for _ in range(2):                       # warm-up: func attributes, head plans, allocator, RCCL's lazy init
-                    whole()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            _drain_watchdog(self.group)
-            # audition of the instantiation (engine.CommEngine._audition: a bad assignment of the graph's branches to hardware queues
-            # replays 2-3x slower for the graph's whole life, and with N ranks one such rank slows every step of all of them).  The
-            # collectives are inside the graph, so every rank must keep the SAME candidate: the candidates' times are MAX-reduced over
-            # the ranks before they are compared.
+            # Every rank must take the SAME form (the collectives are inside the graph: a rank that fell back to eager collectives while
+            # its peers replay captured ones hangs them all), and every rank must keep the SAME candidate of the audition.
+            # So: warm up -> prove the watchdog's list empty -> capture ALL candidates (no eager collective between captures) -> ONE
+            # agreement all-reduce (MIN of "my captures succeeded") -> time the candidates -> ONE all-reduce (MAX) of the time vector.
             from .engine import _GRAPH_AUDITION
-            best, times = None, []
-            for i in range(max(1, _GRAPH_AUDITION)):
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    pack = whole()
-                cand = (graph, slots, pack)
-                if _GRAPH_AUDITION <= 1:
-                    best = (0.0, cand)
-                    break
-                ops.set_slots(slots, [x, out, torch.empty_like(pack)])
-                graph.replay()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    graph.replay()
-                e1.record()
-                e1.synchronize()
-                t = torch.tensor([e0.elapsed_time(e1) / 5.0], dtype=torch.float64, device=dev)
+            n_cand = max(1, _GRAPH_AUDITION)
+            cands, err = [], None
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    pack0 = ops.graph_outputs(dev, B, N, n_loc)[0]
+                    ops.set_slots(slots, [x, out, pack0])
+                    for _ in range(2):                       # warm-up: func attributes, head plans, allocator, RCCL's lazy init
+                        whole()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                self.watchdog_wait_s = _watchdog_idle(self.group)
+                for i in range(n_cand):
+                    with _collectives_captured(), ops.capture() as graph:
+                        pack = whole()
+                    cands.append((graph, slots, pack))
+            except RuntimeError as e:
+                err = e
+            if self.world > 1:
+                ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if float(ok.item()) < 1.0 and err is None:
+                    err = RuntimeError("a peer rank could not capture the sharded step")
+            if err is not None:
+                raise RuntimeError(str(err))
+            times = []
+            if n_cand > 1:
+                for cand in cands:
+                    ops.set_slots(slots, [x, out, torch.empty_like(cand[2])])
+                    cand[0].replay()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        cand[0].replay()
+                    e1.record()
+                    e1.synchronize()
+                    times.append(e0.elapsed_time(e1) / 5.0)
+                t = torch.tensor(times, dtype=torch.float64, device=dev)
                 if self.world > 1:
                     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                t = float(t.item())
-                if self.world > 1 and i + 1 < max(1, _GRAPH_AUDITION):
-                    _drain_watchdog(self.group)              # (the eager all-reduce above is in the watchdog's list; the next capture follows)
-                times.append(round(t, 4))
-                if best is None or t < best[0]:
-                    best = (t, cand)
+                times = [round(float(v), 4) for v in t.tolist()]
+                best = min(range(n_cand), key=lambda i: times[i])
+            else:
+                best = 0
             self.audition_ms = times
-            ent = st.graphs["whole:" + inference] = best[1]
+            ent = st.graphs["whole:" + inference] = cands[best]
         graph, slots, pack = ent
         packc = torch.empty_like(pack)
         ops.set_slots(slots, [x, out, packc])
@@ -444,8 +526,8 @@ class AgentParallelForward:
 #     agent-concatenated batch, agent.py:1108-1111) -- forward sums and backward sums all-reduced between partial sums and finalize;
 #   * value maps and keys are all-gathered DIFFERENTIABLY (backward: the gradient contributions of every rank's loss, summed, this
 #     rank's rows), queries stay local, each rank fuses + decodes + takes the loss of its own query agents;
-#   * parameter gradients are all-reduced (SUM) in one flattened bucket: the global loss is the mean of the ranks' local losses, so
-#     every rank backpropagates local_loss / world.
+#   * parameter gradients are all-reduced (SUM) in one flattened bucket; every rank backpropagates its share of the GLOBAL loss
+#     (_sharded_loss: local sum / global denominator for the size_average cross entropy, local loss / world otherwise).
 # The result equals the unsharded step up to summation order (tests/test_parallel_gpu.py: loss and gradients against the one-GPU step).
 class _AllGatherRows(torch.autograd.Function):
     """y = concat over the ranks (rank order) of x along dim 0; dy -> sum over the ranks of dy, this rank's rows."""
@@ -504,19 +586,58 @@ def agent_parallel_train_forward(model, inputs_local, group=None):
     return pred, prob
 
 
-def agent_parallel_train_step(model, optimizer, loss_fn, inputs_local, labels_local, group=None):
-    """One agent-sharded training step (see the block comment above) -> the GLOBAL loss (mean over the ranks) as a float tensor.
-    labels_local: the labels of this rank's agents, agent-major [n_loc*B, H, W]."""
-    from . import train_ops
+def _sharded_loss(loss_fn, pred, labels_local, group):
+    """-> (the term THIS rank backpropagates, the global loss as a detached float tensor).
+    The pixel-wise cross entropy with size_average (loss.py:5-18, the reference's default) is sum(w_t nll) / sum(w_t) over the kept
+    pixels of the WHOLE batch; with ignore_index pixels or class weights the ranks' denominators differ, so the mean of the ranks' means
+    is not it.  For cross_entropy2d (plain or functools.partial of it) each rank takes its local SUM, the denominators
+    are all-reduced, and the rank backpropagates local_sum / global_denominator.  Any other loss: the mean of the ranks' values
+    (exact for losses that are a mean over images of per-image terms with equal images per rank, e.g. bootstrapped_cross_entropy2d)."""
+    import functools
+    from . import loss as _loss
     world = dist.get_world_size(group)
-    train_ops.set_sync_bn(True, group)
+    base, kw = loss_fn, {}
+    while isinstance(base, functools.partial):
+        kw = {**base.keywords, **kw}
+        if base.args:
+            base = None
+            break
+        base = base.func
+    if base is _loss.cross_entropy2d and kw.get("size_average", True) and set(kw) <= {"weight", "size_average"}:
+        weight = kw.get("weight")
+        n_cls = pred.shape[1]
+        local_sum = _loss.cross_entropy2d(pred, labels_local, weight=weight, size_average=False)
+        lab = labels_local.reshape(-1).long()
+        valid = (lab >= 0) & (lab < n_cls) & (lab != _loss.IGNORE_INDEX)
+        if weight is None:
+            denom = valid.sum().double().reshape(1)
+        else:
+            wv = weight.to(device=lab.device, dtype=torch.float64)
+            denom = (wv[lab.clamp(0, n_cls - 1)] * valid.double()).sum().reshape(1)
+        tot = torch.cat([denom, local_sum.detach().double().reshape(1)])
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        d = tot[0].clamp_min(1e-30)
+        return local_sum / d.float(), (tot[1] / d).float()
+    local = loss_fn(pred, labels_local)
+    g = local.detach().clone().float().reshape(1)
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return local / world, (g / world).reshape(())
+
+
+def agent_parallel_train_step(model, optimizer, loss_fn, inputs_local, labels_local, group=None):
+    """One agent-sharded training step (see the block comment above) -> the GLOBAL loss as a float tensor (for cross_entropy2d: the
+    size_average loss over every rank's pixels with the global denominator, see _sharded_loss).
+    labels_local: the labels of this rank's agents, agent-major [n_loc*B, H, W].  The caller's sync-BN setting is restored on exit;
+    a train-mode BatchNorm that cannot take the synchronised HIP path raises (train_ops.bn_act) instead of normalising locally."""
+    from . import train_ops
+    prev = train_ops.set_sync_bn(True, group)
     try:
         optimizer.zero_grad(set_to_none=True)
         pred, _ = agent_parallel_train_forward(model, inputs_local, group)
-        loss = loss_fn(pred, labels_local)
-        (loss / world).backward()
+        term, global_loss = _sharded_loss(loss_fn, pred, labels_local, group)
+        term.backward()
     finally:
-        train_ops.set_sync_bn(False)
+        train_ops.restore_sync_bn(prev)
     params = [p for p in model.parameters() if p.grad is not None]
     if params:
         flat = torch.cat([p.grad.reshape(-1).float() for p in params])         # one bucket: one collective
@@ -527,6 +648,4 @@ def agent_parallel_train_step(model, optimizer, loss_fn, inputs_local, labels_lo
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
     optimizer.step()
-    g = loss.detach().clone().float()
-    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-    return g / world
+    return global_loss

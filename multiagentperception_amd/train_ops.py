@@ -220,7 +220,15 @@ def set_sync_bn(enabled, group=None):
     agent-concatenated batch (agent.py:1108-1111), so ranks that each hold some of the agents must add their per-channel sums.
     set_sync_bn(True[, group]) / set_sync_bn(False).  Needs an initialised process group."""
     global _sync_bn_group
+    prev = _sync_bn_group
     _sync_bn_group = (group,) if enabled else None
+    return prev
+
+
+def restore_sync_bn(prev):
+    """put back what an earlier set_sync_bn() returned (agent_parallel_train_step restores its caller's setting)"""
+    global _sync_bn_group
+    _sync_bn_group = prev
 
 
 class _BnActFn(torch.autograd.Function):
@@ -277,6 +285,12 @@ def bn_act(bn, x, relu, residual=None):
         # (num_batches_tracked is incremented by the finalize kernel of the forward: 47 one-element launches per step otherwise)
         return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu, bn.momentum, bn.eps,
                               bn.num_batches_tracked)
+    if _sync_bn_group is not None and bn.training:
+        # agent-sharded training: a train-mode BatchNorm on the stock path would normalise with THIS rank's statistics only and the
+        # step would silently stop being the unsharded one -- refuse instead
+        raise ops.W2CError("sync-BN is on (agent-sharded training) but this train-mode BatchNorm cannot take the HIP path (backend %r, "
+                           "input %s %s, channels_last %s): its statistics would be local to the rank"
+                           % (_backend, tuple(x.shape), x.dtype, x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)))
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -330,6 +344,13 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, optimizer, loss_fn, example_inputs, example_labels, forward_kwargs=dict(training=True, MO_flag=True))
         loss = step(inputs, labels)          # copies the batch into the captured step's static buffers, replays, returns the loss tensor
 
+    Constructing the object runs `warmup` real steps on the example batch (func attributes, workspaces, autograd buffers, optimizer
+    state have to exist before the capture) -- the model's parameters and buffers (BN running statistics, num_batches_tracked) and the
+    optimizer's state are SNAPSHOT before and RESTORED IN PLACE after them, so construction leaves the training state where it was:
+    k calls of the object equal k eager steps.  (State tensors the optimizer first creates during the warm-up -- momentum buffers, Adam
+    moments, capturable step counters -- are zeroed: that equals a fresh optimizer for every optimizer whose first step is not a
+    special case; SGD with dampening != 0 is one.)  __call__ returns a CLONE of the captured step's loss tensor.
+
     Restrictions (PyTorch's whole-network capture rules): fixed input shapes; no host synchronisation inside the step (the loss's
     out-of-range-label check is skipped while capturing: run one eager step per epoch, or W2C_CHECK_LABELS=1 eager runs, to keep it);
     the optimizer must not read the host (SGD / momentum SGD are fine; Adam needs capturable=True); parameters must not be replaced
@@ -351,6 +372,11 @@ class GraphedTrainStep:
             optimizer.step()
             return loss
 
+        # snapshot: the warm-up steps below are real steps
+        saved_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        saved_opt = {}
+        for p_, st_ in optimizer.state.items():
+            saved_opt[p_] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st_.items()}
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -358,13 +384,27 @@ class GraphedTrainStep:
                 one()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        # restore IN PLACE (the captured step keeps the addresses): parameters, buffers, optimizer state
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(saved_model[k])
+            for p_, st_ in optimizer.state.items():
+                old = saved_opt.get(p_, {})
+                for k, v in st_.items():
+                    if torch.is_tensor(v):
+                        if k in old and torch.is_tensor(old[k]):
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()
+                    elif k in old:
+                        st_[k] = old[k]
+        torch.cuda.synchronize(dev)
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with ops.capture(thread_local=False) as self.graph:
             self.loss = one()
 
     def __call__(self, inputs, labels):
         self.x.copy_(inputs, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self.graph.replay()
-        return self.loss
+        return self.loss.clone()                     # caller-owned: the next replay overwrites self.loss

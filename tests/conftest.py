@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """GPU runs: a fatal signal inside a runtime library prints its NATIVE call stack (w2c_debug_install_crash_backtrace) before
+    Python's faulthandler prints the Python one -- round 4's SIGSEGV left only the Python half in the driver's log."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from multiagentperception_amd import _native
+            _native.lib().w2c_debug_install_crash_backtrace()
+    except Exception as e:                      # a debug aid must never take the suite down
+        print("conftest: crash backtrace handler not installed (%r)" % (e,))

@@ -280,7 +280,7 @@ def test_layer1_kernel_forms_are_bit_identical_with_residual_and_relu():
             assert torch.equal(a, c) and torch.equal(b, a), (res is not None, relu)
 
 
-@pytest.mark.parametrize("M", [1, 20, 32, 33, 64])
+@pytest.mark.parametrize("M", [1, 20, 32, 33, 64, 65, 100, 128])
 def test_head_fc0_on_the_f32_matrix_pipe_matches_fp64_and_is_row_count_independent(M):
     """w2c_head_fc0_mfma_f32 (+ the split-K sum of w2c_head_tail2p_f32): fc.0 of both heads as v_mfma_f32_32x32x2_f32 over
     fragment-packed f32 weights.  The MFMA is exact f32, so the only difference from an f64 evaluation is f32 summation order
@@ -299,6 +299,11 @@ def test_head_fc0_on_the_f32_matrix_pipe_matches_fp64_and_is_row_count_independe
     if M > 1:                                                            # row 0 alone == row 0 inside the batch, bit for bit
         one = ops.head_fc0_mfma(x[:1].contiguous().to(_dev()), K, 1, K, ops.pack_fc0_frag(w0).to(_dev()), O)
         assert torch.equal(one[:, 0], part[:, 0])
+    if M > 64:                  # any row count takes this kernel (N*B > 64 unsharded vs a <= 64-row shard): a shard of the
+        lo, hi = M - 40, M      # LAST rows alone (another row block, another clamp) == the same rows inside the batch, bit for bit
+        shard = ops.head_fc0_mfma(x[lo:hi].contiguous().to(_dev()), K, hi - lo, K, ops.pack_fc0_frag(w0).to(_dev()), O)
+        assert torch.equal(shard, part[:, lo:hi])
+        assert ops.head_fc0_supported(M, K, O) and ops.head_fc0_supported(8, K, O)
     # the tail launch on the partials == the tail launch on the finished fc.0 output it forms from them
     tails = []
     for h in range(2):

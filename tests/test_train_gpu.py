@@ -456,3 +456,54 @@ def test_graph_captured_training_step_reproduces_the_eager_step():
         assert grads.keys() == ref_grads.keys()
         for k in grads:
             assert torch.equal(grads[k], ref_grads[k]), k
+
+
+def test_graphed_step_leaves_training_state_untouched_and_k_steps_equal_k_eager_steps():
+    """constructing GraphedTrainStep runs real warm-up steps; they must not leak into the training state.  With lr > 0 and
+    momentum: (1) parameters, BN buffers and optimizer state after construction equal those before it; (2) k graphed steps leave the
+    same weights, BN statistics and momentum buffers as k eager steps of a twin model, bit for bit (every kernel is deterministic);
+    (3) the returned losses are caller-owned (a later step does not overwrite an earlier loss)."""
+    import copy
+    from oracle import filler
+    from ptsemseg.models import get_model
+    from multiagentperception_amd import train_ops
+    from multiagentperception_amd.loss import cross_entropy2d
+    n, b, s = 3, 1, 128
+    train_ops.set_train_backend("hip")
+    model = get_model(_cfg("MIMOcom", n, s, True), 11)
+    filler.apply_to_module(model)
+    model = model.to(_dev()).train()
+    twin = copy.deepcopy(model)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    opt_twin = torch.optim.SGD(twin.parameters(), lr=1e-3, momentum=0.9)
+    batches = []
+    for seed in (51, 52, 53):
+        batches.append((torch.from_numpy(filler.synthetic_frames(b, n, s, s, seed)).to(_dev()),
+                        torch.from_numpy(filler.synthetic_labels(b * n, s, s, seed)).to(_dev())))
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    step = train_ops.GraphedTrainStep(model, opt, cross_entropy2d, batches[0][0], batches[0][1],
+                                      forward_kwargs=dict(training=True, MO_flag=True))
+    after = model.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), "construction changed %s" % k
+    for st in opt.state.values():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                assert float(v.abs().max()) == 0.0, "optimizer state %s is not fresh after construction" % k
+    losses, ref_losses = [], []
+    for x, labels in batches:
+        losses.append(step(x, labels))
+        opt_twin.zero_grad(set_to_none=True)
+        loss = cross_entropy2d(twin(x, training=True, MO_flag=True)[0], labels)
+        loss.backward()
+        opt_twin.step()
+        ref_losses.append(loss.detach().clone())
+    torch.cuda.synchronize()
+    for got, ref in zip(losses, ref_losses):
+        assert torch.equal(got, ref)                        # all three: the first two were not overwritten by the later replays
+    assert len({float(l) for l in losses}) == 3
+    sd, sd_twin = model.state_dict(), twin.state_dict()
+    for k in sd:
+        assert torch.equal(sd[k], sd_twin[k]), k
+    for (p, st), (pt, stt) in zip(opt.state.items(), opt_twin.state.items()):
+        assert torch.equal(st["momentum_buffer"], stt["momentum_buffer"])
