@@ -45,7 +45,11 @@ import tempfile
 import time
 
 import numpy as np
-import torch
+
+# ProcessGroupNCCL's flight recorder must exist when the process group is created: the sharded one-graph step proves the watchdog's list empty
+# through it before it captures collectives (multiagentperception_amd/parallel.py _watchdog_idle); without it the step takes the 3-segment form
+os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -320,8 +320,9 @@ int w2c_debug_stamp(void* slot, w2c_stream_t stream);
 /* Debug (round 5): install handlers for SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL that write the NATIVE call stack of the faulting
    thread to stderr (backtrace_symbols_fd: async-signal-safe) and then chain to whatever handler was installed before (Python's
    faulthandler under pytest), so that a crash inside a runtime library is named by its frame, not only by the Python line above it.
+   fd: where to write (< 0: stderr; pytest captures fd 2, so tests/conftest.py passes the descriptor the faulthandler plugin kept).
    tests/conftest.py calls it once; the product path never does.  Returns W2C_OK. */
-int w2c_debug_install_crash_backtrace(void);
+int w2c_debug_install_crash_backtrace(int fd);
 
 /* ---- K5: Linear (+ReLU) for the key/query heads (agent.py:150-159,167-178).
  * x : [M, K] bf16 (x_is_bf16=1, row stride x_stride elements) or f32
@@ -411,16 +412,18 @@ int w2c_head_tail2p_f32(const float* part, int n_part, long long part_stride, co
 
 /* K6 + K7 with the decoder's first conv taken through the fusion by LINEARITY (round 4; agent.py:276-284, backbone.py:150-152):
  *   u    : f32 NHWC rows [N*B][hw][u_cstride], agent-major: U[k] = conv0 WITHOUT bias of agent k's value map, channels [0, C);
- *          MIMOcomWho (decoder input cat(fused, V[q]), agent.py:1382): channels [own_off, own_off + C) = the conv of V with the
- *          second half of conv0's filters; own_off < 0: none
- *   out  : bf16 NHWC rows [q_n*B][hw][out_cstride]: row (q*B+b) = relu(sum_k coef[b,k,q] * u[k*B+b] (+ u_own[(q_lo+q)*B+b]) + bias)
+ *   u_own: NULL, or (MIMOcomWho: decoder input cat(fused, V[q]), agent.py:1382) f32 rows [q_n*B][hw][own_cstride] of the LOCAL query
+ *          agents: the conv of V[q] with the second half of conv0's filters, channels [0, C).  A separate operand (round 5) so that an
+ *          agent-parallel rank all-gathers U alone: U_own never leaves the rank.  (The one-GPU engine passes a view into the same
+ *          tensor as u.)
+ *   out  : bf16 NHWC rows [q_n*B][hw][out_cstride]: row (q*B+b) = relu(sum_k coef[b,k,q] * u[k*B+b] (+ u_own[q*B+b]) + bias)
  *          = relu(conv0(fused map)), summed in f32 and rounded once; graph outputs as in w2c_comm_graph_fuse.
  *   pack2: optional [indirect-capable] second copy of the graph outputs, packed: prob f32 [B,N,q_n] at byte 0, action i64 [B,q_n] at
  *          act_off, nnz i32 [B] at nnz_off (act_off % 8 == 0, nnz_off % 4 == 0) -- a captured forward's caller-owned outputs. */
 int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
                           float thres, float tie_bias, int q_lo, int q_n,
                           float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
-                          const float* u, int u_cstride, int hw, int C, int own_off, const float* bias,
+                          const float* u, int u_cstride, int hw, int C, const float* u_own, int own_cstride, const float* bias,
                           uint16_t* out, int out_cstride, void* pack2, long long act_off, long long nnz_off, w2c_stream_t stream);
 
 /* ---- Indirect operands (round 4).  The module boundary hands the forward a caller-owned input tensor and returns caller-owned

@@ -36,7 +36,7 @@ SIGNATURES = {
     "w2c_conv3x3_wreg_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _vp],
     "w2c_debug_conv_timeline": [_vp],
     "w2c_debug_stamp": [_vp, _vp],
-    "w2c_debug_install_crash_backtrace": [],
+    "w2c_debug_install_crash_backtrace": [_i],
     "w2c_debug_conv_span": [_vp],
     "w2c_conv_igemm_fp8": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _vp, _i, _f,
                            _vp, _i, _vp],
@@ -74,7 +74,7 @@ SIGNATURES = {
     "w2c_comm_graph_fuse": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_head_fc0_mfma_f32": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "w2c_head_tail2p_f32": [_vp, _i, _ll, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "w2c_comm_graph_fuse_u": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _ll, _ll, _vp],
+    "w2c_comm_graph_fuse_u": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _ll, _ll, _vp],
     "w2c_fuse_values": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "w2c_set_slots": [_vp, _i, _vp, _vp],
     "w2c_copy_to_slot": [_vp, _ll, _vp, _vp],

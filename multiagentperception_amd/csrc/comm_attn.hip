@@ -750,7 +750,8 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
                                                            int B, int N, int Dq, int who, int mode, float thres, float tie_bias,
                                                            int q_lo, int q_n, float* __restrict__ prob, float* __restrict__ coef,
                                                            int64_t* __restrict__ action, int32_t* __restrict__ nnz,
-                                                           const float* __restrict__ u, int ucs, int hw, int C, int own_off,
+                                                           const float* __restrict__ u, int ucs, int hw, int C,
+                                                           const float* __restrict__ u_own, int own_cs,
                                                            const float* __restrict__ bias, uint16_t* __restrict__ out, int ocs,
                                                            char* pack2_arg, long act_off, long nnz_off) {
     // pack2 (optional, indirect-capable): a second, caller-owned copy of the packed prob | action | nnz (same layout as the buffer
@@ -836,8 +837,8 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] = fmaf(c, uk[k][e], acc[e]);
                 }
-                if (own_off >= 0) {
-                    const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(u + ((size_t)((q_lo + ql) * B + b) * hw + px) * ucs + own_off + cg * 4);
+                if (u_own) {                                           // rows of the LOCAL queries: (ql * B + b)
+                    const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(u_own + ((size_t)(ql * B + b) * hw + px) * own_cs + cg * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] += o4[e];
                 }
@@ -858,8 +859,8 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(c, v4[e], acc[e]);
             }
-            if (own_off >= 0) {
-                const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(u + ((size_t)((q_lo + ql) * B + b) * hw + px) * ucs + own_off + cg * 4);
+            if (u_own) {
+                const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(u_own + ((size_t)(ql * B + b) * hw + px) * own_cs + cg * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += o4[e];
             }
@@ -1026,21 +1027,22 @@ extern "C" int w2c_comm_graph_fuse(const float* query, const float* tproj, int B
 extern "C" int w2c_comm_graph_fuse_u(const float* query, const float* tproj, int B, int N, int Dq, int who, int mode,
                                      float thres, float tie_bias, int q_lo, int q_n,
                                      float* prob, float* coef, int64_t* action, int32_t* nnz_offdiag,
-                                     const float* u, int u_cstride, int hw, int C, int own_off, const float* bias,
+                                     const float* u, int u_cstride, int hw, int C, const float* u_own, int own_cstride,
+                                     const float* bias,
                                      uint16_t* out, int out_cstride, void* pack2, long long act_off, long long nnz_off, w2c_stream_t stream) {
     w2c_clear_error();
     if (!tproj || !prob || !coef || !action || !nnz_offdiag || !u || !bias || !out) return W2C_E_ARG;
     if (B <= 0 || N <= 0 || N > MAXN || Dq <= 0 || mode < 0 || mode > 2) return W2C_E_ARG;
     if (q_lo < 0 || q_n <= 0 || q_lo + q_n > N) return W2C_E_ARG;
     if (hw <= 0 || C <= 0 || (C % 4) != 0 || (u_cstride % 4) != 0 || (out_cstride % 4) != 0 || u_cstride < C || out_cstride < C) return W2C_E_ARG;
-    if (own_off >= 0 && ((own_off % 4) != 0 || own_off + C > u_cstride)) return W2C_E_ARG;
+    if (u_own && ((own_cstride % 4) != 0 || own_cstride < C || (reinterpret_cast<uintptr_t>(u_own) & 15))) return W2C_E_ARG;
     if ((reinterpret_cast<uintptr_t>(u) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return W2C_E_ARG;
     const int total = hw * (C / 4);
     int bx = (total + 255) / 256;
     if (bx > 1024) bx = 1024;
     const size_t lds = (size_t)N * q_n * 4 + 16;
     hipLaunchKernelGGL(graph_fuse_u_kernel, dim3(bx, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), query, tproj, B, N, Dq,
-                       who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag, u, u_cstride, hw, C, own_off < 0 ? -1 : own_off,
+                       who, mode, thres, tie_bias, q_lo, q_n, prob, coef, action, nnz_offdiag, u, u_cstride, hw, C, u_own, own_cstride,
                        bias, out, out_cstride, reinterpret_cast<char*>(pack2), (long)act_off, (long)nnz_off);
     return w2c_launch_status();
 }

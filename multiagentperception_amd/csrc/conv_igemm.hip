@@ -36,10 +36,10 @@
 #include <cstring>
 
 static const char* const kOptionNames[W2C_OPT_COUNT] = {"W2C_XCD2D", "W2C_NO_S2PATCH", "W2C_STEM_WGS", "W2C_STEM_FORM", "W2C_STEM_BAND",
-                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_WREG_SMALL", "W2C_S2REGH", "W2C_UPS_LDS_KB", "W2C_LDS_PAD_KB"};
+                                                        "W2C_STEM_WAVES", "W2C_WGRAD_PATCH", "W2C_INWG_SPLITK", "W2C_WREG_MINCIN", "W2C_WREG_FORM", "W2C_REGW_FORM", "W2C_REGH_WGS", "W2C_REGH_FORM", "W2C_L1_FORM", "W2C_S2WREG_FORM", "W2C_S2REGH"};
 static std::atomic<int> g_options[W2C_OPT_COUNT];
 static const bool g_options_seeded = [] {
-    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 0, 1, 0, 0};
+    const int defaults[W2C_OPT_COUNT] = {1, 0, 0, 0, 8, 8, 1, 1, 256, 0, 1, 0, 0, 54, 1, 1};
     for (int i = 0; i < W2C_OPT_COUNT; ++i) {
         const char* e = getenv(kOptionNames[i]);            // once, at library load
         g_options[i].store(e ? atoi(e) : defaults[i]);
@@ -1921,7 +1921,7 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20) && 2 * wbytes >= xbytes)) && groups == 2 && !(a.ntm & 1) &&
               !(a.ntn & 1) && (a.ntm * a.ntn) % 4 == 0;
     if (a.xcd2d) grid = dim3(a.ntm * a.ntn * 2, 1);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), w2c_padded_lds(lds), s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, WM, WN, STAGES, PB, F8>), grid, dim3(64 * WM * WN), lds, s, a);
     return w2c_launch_status();
 }
 
@@ -2270,9 +2270,8 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 83: return launch_wreg<1, 2>(a, groups, s);
         case 93: return launch_wreg<1, 4, 0, 4>(a, groups, s);   // 81 with the weights 4 / 2 K-steps ahead instead of 8
         case 94: return launch_wreg<1, 4, 0, 2>(a, groups, s);
-        // 32 channels per wave: 2 x 4 = 8 waves on the same 128-pixel x 64-channel workgroup tile (bit-identical to 93 / 94)
-        case 95: return launch_wreg<2, 4, 0, 4, 1>(a, groups, s);
-        case 96: return launch_wreg<2, 4, 0, 2, 1>(a, groups, s);
+        // (round 4, removed in round 5: 32 channels per wave -- 8 waves on the same workgroup tile, bit-identical -- for the small launches:
+        //  +-8 % alone, slower in every forward (profiles/r04_rank_shapes.txt): those launches are not short of waves)
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
         case 50: return launch_regw_any(a, groups, s);
         case 52: return launch_regw2_any(a, groups, s);
@@ -2472,16 +2471,8 @@ extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int
         return W2C_E_ARG;
     if (form == 0) {
         form = wreg_form(H, W, Cin, Cout);
-        // W2C_WREG_SMALL > 0: launches with fewer tiles than that take the 32-channels-per-wave form (twice the waves on the same
-        // workgroup tiles, bit-identical -- so this choice MAY look at M).  OFF by default: alone the form is within +-8 % of form 93
-        // on the small launches (tools/bench_conv.py: policy conv2 16.7 vs 17.9 us, cfg-3 rank layer4 16.6 vs 17.9, policy conv1
-        // 30.7 vs 30.0), in the forwards it loses (tools/ab_wreg_small.sh, 3 interleaved pairs: cfg-3 rank 0.603 vs 0.583 ms, cfg-4
-        // rank 0.917 vs 0.903, cfg 2 1.036 vs 1.033) -- these launches are not short of waves.  Touching the wave's weight lines up
-        // front (every K-step's weight load as a simultaneous first touch was the other suspect) made every launch 6 us slower.
-        const int small = w2c_option(W2C_OPT_WREG_SMALL);
-        if (form == 93 && small > 0 && (long)M * (H / 8) * (W / 16) * (Cout / 64) * groups < small) form = 96;
     }
-    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94 && form != 95 && form != 96 && form != 54) return W2C_E_ARG;
+    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94 && form != 54) return W2C_E_ARG;
     w2c_clear_error();
     return launch_variant(form, a, groups, reinterpret_cast<hipStream_t>(stream));
 }

@@ -429,6 +429,6 @@ int launch_s2wreg(ConvArgs& a, int groups, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_wreg_kernel<NN, KS, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv3x3s2_wreg_kernel<NN, KS, DW>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), w2c_padded_lds(lds), s, a);
+    hipLaunchKernelGGL((conv3x3s2_wreg_kernel<NN, KS, DW>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
     return w2c_launch_status();
 }

@@ -387,6 +387,6 @@ int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
     const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);
     const long wbytes = (long)a.Cout * 9 * a.Cin * 2;
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20))) && !(a.ntm & 1) && !(a.ntn & 3);
-    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW, NB>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), w2c_padded_lds(lds), s, a);
+    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW, NB>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
     return w2c_launch_status();
 }

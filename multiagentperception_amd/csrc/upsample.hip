@@ -246,29 +246,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MULTI ? 1 :
             const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
             if (labels) *reinterpret_cast<uint32_t*>(obase + (size_t)ry * W) = packed;
             if (CONF) {
-                // this row's four bins n * gt + pred (NOBIN: gt outside [0, n)), kept for the histogram step behind the rows
+                if (MULTI) {
+                    // this row's four bins n * gt + pred (NOBIN: gt outside [0, n)), kept for the histogram step behind the rows
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int g = (int)((gt8[CONF ? ry : 0] >> (8 * e)) & 0xFF);        // (u8 labels: 255 >= n is outside too: n <= 64)
-                    const unsigned b = g < ncls ? (unsigned)(g * ncls + bi[e]) : NOBIN;
-                    if (MULTI) binp[MULTI ? 2 * ry + (e >> 1) : 0] |= b << (16 * (e & 1));
-                    else binp[MULTI ? 0 : ry] |= b << (8 * e);
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = (int)((gt8[CONF ? ry : 0] >> (8 * e)) & 0xFF);        // (u8 labels: 255 >= n is outside too: n <= 64)
+                        const unsigned b = g < ncls ? (unsigned)(g * ncls + bi[e]) : NOBIN;
+                        binp[MULTI ? 2 * ry + (e >> 1) : 0] |= b << (16 * (e & 1));
+                    }
+                } else {
+                    binp[MULTI ? 0 : ry] = packed;           // <= 12 classes: the row's four PREDICTIONS; the bins are formed behind the rows
                 }
             }
         }
         }   // class chunks
-        if (CONF) {
-            // Histogram step, once per thread (the first form did this per ROW with wave-wide ballots: 8 x the scalar traffic, and its
-            // unrolled slow paths made the kernel 2.2x the labels-only one).  An upsampled x32 prediction is constant over almost every
-            // 8 x 4 block and real label maps are piecewise constant: a thread whose 32 pixels share ONE bin adds 32 with one LDS atomic,
-            // a wave whose 64 threads all do (the common case inside a segment) adds 2048 with one; only threads on a border (or
-            // noise-like labels: the synthetic benchmark's) count their pixels one by one.
-            constexpr int NP = MULTI ? 2 * ARG_ROWS : ARG_ROWS;
-            const unsigned first = binp[0] & NOBIN;
-            const unsigned rep = MULTI ? first * 0x00010001u : first * 0x01010101u;
+        if (CONF && !MULTI) {
+            // Histogram step, once per thread, <= 12 classes (round 5; the round-4 form added a thread's 32 pixels one LDS atomic at a time
+            // unless all 32 shared ONE bin: with noise-like ground truth -- the synthetic benchmark's -- that is 2048 atomics per wave on
+            // 121 addresses: SQ_LDS_BANK_CONFLICT 77 %).  An upsampled x32 PREDICTION is constant over almost every 8 x 4 block, whatever
+            // the ground truth looks like: a thread whose 32 pixels share one prediction counts its ground-truth classes in REGISTERS
+            // (12 byte counters in three words); a wave whose 64 threads share that prediction (the common case) sums the counters with
+            // shuffles and lane g adds class g's total with ONE atomic -- <= 12 atomics per wave, all on different addresses.  Threads on
+            // a prediction border fall back to per-pixel atomics.  Integer counts: the histogram is exact either way.
+            const unsigned p0 = binp[0] & 0xFFu;
+            const unsigned rep = p0 * 0x01010101u;
             unsigned diff = 0;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) diff |= binp[i] ^ rep;
+            for (int i = 0; i < ARG_ROWS; ++i) diff |= binp[i] ^ rep;
+            const bool puni = diff == 0;
+            const int lane = (int)(threadIdx.x & 63);
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+            const unsigned lead = (unsigned)__builtin_amdgcn_readfirstlane((int)p0);
+            const bool wave_uni = active == ~0ull && __builtin_amdgcn_ballot_w64(puni && p0 == lead) == active;
+            if (puni) {
+                unsigned c0 = 0, c1 = 0, c2 = 0;             // byte counters of ground-truth classes 0-3 | 4-7 | 8-11 (each <= 32)
+#pragma unroll
+                for (int ry = 0; ry < ARG_ROWS; ++ry)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned g = (gt8[CONF ? ry : 0] >> (8 * e)) & 0xFFu;   // >= ncls (incl. the 0xFF of an out-of-range label): dropped
+                        const unsigned inc = g < (unsigned)ncls ? 1u << ((g & 3u) * 8u) : 0u;
+                        const unsigned wsel = g >> 2;
+                        c0 += wsel == 0u ? inc : 0u;
+                        c1 += wsel == 1u ? inc : 0u;
+                        c2 += wsel == 2u ? inc : 0u;
+                    }
+                if (wave_uni) {
+                    // 16-bit pairs {class 4w + b, class 4w + b + 2}: 64 lanes x 32 = 2048 fits
+                    unsigned wv[6] = {c0 & 0x00FF00FFu, (c0 >> 8) & 0x00FF00FFu, c1 & 0x00FF00FFu, (c1 >> 8) & 0x00FF00FFu,
+                                      c2 & 0x00FF00FFu, (c2 >> 8) & 0x00FF00FFu};
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) wv[i] += (unsigned)__shfl_xor((int)wv[i], off, 64);
+                    unsigned mine = 0;
+#pragma unroll
+                    for (int g = 0; g < ARG_MAXC; ++g) {
+                        const unsigned src = wv[2 * (g >> 2) + (g & 1)];
+                        const unsigned cnt = (g & 2) ? src >> 16 : src & 0xFFFFu;
+                        mine = lane == g ? cnt : mine;
+                    }
+                    if (lane < ncls && mine) atomicAdd(&lh[lane * ncls + (int)lead], mine);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < ARG_MAXC; ++g) {
+                        const unsigned src = g < 4 ? c0 : g < 8 ? c1 : c2;
+                        const unsigned cnt = (src >> (8 * (g & 3))) & 0xFFu;
+                        if (g < ncls && cnt) atomicAdd(&lh[g * ncls + (int)p0], cnt);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ry = 0; ry < ARG_ROWS; ++ry)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned g = (gt8[CONF ? ry : 0] >> (8 * e)) & 0xFFu;
+                        const unsigned pr = (binp[MULTI ? 0 : ry] >> (8 * e)) & 0xFFu;
+                        if (g < (unsigned)ncls) atomicAdd(&lh[g * ncls + pr], 1u);
+                    }
+            }
+        }
+        if (CONF && MULTI) {
+            // > 12 classes: packed 16-bit bins, per-thread / per-wave uniform fast paths (the round-4 form)
+            constexpr int NP = 2 * ARG_ROWS;
+            const unsigned first = binp[0] & NOBIN;
+            const unsigned rep = first * 0x00010001u;
+            unsigned diff = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) diff |= binp[MULTI ? i : 0] ^ rep;
             const bool uni = diff == 0;
             const int lane = (int)(threadIdx.x & 63);
             const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
@@ -282,8 +347,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MULTI ? 1 :
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int e = 0; e < (MULTI ? 2 : 4); ++e) {
-                        const unsigned b = (binp[i] >> ((MULTI ? 16 : 8) * e)) & NOBIN;
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned b = (binp[MULTI ? i : 0] >> (16 * e)) & NOBIN;
                         if (b != NOBIN) atomicAdd(&lh[b], 1u);
                     }
             }
@@ -433,10 +498,7 @@ extern "C" int w2c_upsample_bilinear32(const float* low, int M, int h, int w, in
     w2c_clear_error();
     if (!low || !out || M <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || low_cstride < n_classes) return W2C_E_ARG;
     if ((size_t)h * w * 4 > 64 * 1024) return W2C_E_ARG;
-    // W2C_UPS_LDS_KB (A/B): pad the workgroup's LDS request to that many KB = cap the workgroups resident per CU (a write-bound launch:
-    // does it need 8 workgroups per CU, and what do they cost the next forward's front in power?)
-    size_t lds = (size_t)h * w * 4;
-    if (const int kb = w2c_option(W2C_OPT_UPS_LDS_KB); kb > 0 && (size_t)kb * 1024 > lds && kb <= 64) lds = (size_t)kb * 1024;
+    const size_t lds = (size_t)h * w * 4;
     hipLaunchKernelGGL(upsample32_kernel, dim3(h, n_classes, M), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), low, h, w, low_cstride, n_classes, out);
     return w2c_launch_status();
@@ -591,14 +653,15 @@ extern "C" int w2c_copy_to_slot(const void* src, long long nbytes, void* dst, w2
 #include <unistd.h>
 namespace {
 struct sigaction g_prev_sa[65];
+int g_crash_fd = 2;
 void crash_backtrace_handler(int sig, siginfo_t* info, void* uc) {
     void* frames[96];
     const int n = backtrace(frames, 96);
     static const char head[] = "\n==== libw2c_hip: native backtrace of the faulting thread ====\n";
-    (void)!write(2, head, sizeof(head) - 1);
-    backtrace_symbols_fd(frames, n, 2);
+    (void)!write(g_crash_fd, head, sizeof(head) - 1);
+    backtrace_symbols_fd(frames, n, g_crash_fd);
     static const char tail[] = "==== end of native backtrace ====\n";
-    (void)!write(2, tail, sizeof(tail) - 1);
+    (void)!write(g_crash_fd, tail, sizeof(tail) - 1);
     const struct sigaction& prev = g_prev_sa[sig];
     if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction) {
         prev.sa_sigaction(sig, info, uc);
@@ -609,7 +672,8 @@ void crash_backtrace_handler(int sig, siginfo_t* info, void* uc) {
     raise(sig);
 }
 }  // namespace
-extern "C" int w2c_debug_install_crash_backtrace(void) {
+extern "C" int w2c_debug_install_crash_backtrace(int fd) {
+    g_crash_fd = fd >= 0 ? fd : 2;
     void* warm[4];
     (void)backtrace(warm, 4);                            // loads libgcc's unwinder now, outside any signal handler
     static const int sigs[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL};

@@ -109,12 +109,7 @@ enum W2COption {
     W2C_OPT_REGH_FORM,        // 0 (default) | 1 | 2 | 3: A/B forms of the two-waves-per-SIMD layer1 kernel (conv_regh.inl)
     W2C_OPT_L1_FORM,          // layer1 (Cin = Cout = 64) through w2c_conv3x3_wreg_bf16: 54 (default) = conv3x3_c64_regh_kernel | 0 = not offered
     W2C_OPT_S2WREG_FORM,      // stride-2 block fronts (conv_s2wreg.inl): 1 (default) .. 4: that kernel form wherever it fits | 0 = not offered (ring kernel)
-    W2C_OPT_WREG_SMALL,       // 0 (default) = never | n: wreg launches with fewer 128-px x 64-ch tiles than n take the 32-channels-per-wave form (96)
     W2C_OPT_S2REGH,           // 1 (default) | 0: the first stride-2 block front (64 -> 128) on the persistent weights-stationary kernel (conv_s2regh.inl)
-    W2C_OPT_UPS_LDS_KB,       // 0 (default) | n <= 64: LDS request of the x32 upsample's workgroups padded to n KB (A/B: fewer resident workgroups)
-    W2C_OPT_LDS_PAD_KB,       // 0 (default) | n <= 160: the halo-patch / weights-to-registers conv launches request at least n KB of LDS (A/B: engine's
-                              // W2C_VALUE_LDS_KB pads the VALUE chain's launches so that one CU never holds two of them -- the policy chain gets the other slot)
     W2C_OPT_COUNT
 };
 int w2c_option(int id);
-static inline int w2c_padded_lds(int lds) { const int kb = w2c_option(W2C_OPT_LDS_PAD_KB); return (kb > 0 && kb <= 160 && kb * 1024 > lds) ? kb * 1024 : lds; }

@@ -37,8 +37,6 @@ def _fold_bn(bn, conv_bias=None):
 
 _USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
 _GRAPH_AUDITION = int(os.environ.get('W2C_GRAPH_AUDITION', '4'))   # captures a one-graph forward may audition (CommEngine._audition)
-_VALUE_LAG = int(os.environ.get('W2C_VALUE_LAG', '0'))   # A/B: the value chain starts behind block k of the policy chain (0 = together)
-_HEADS_AFTER_JOIN = bool(os.environ.get('W2C_HEADS_AFTER_JOIN'))
 # the remaining A/B switches, read once at import (never on the launch path)
 _NO_SPLITK = bool(os.environ.get('W2C_NO_SPLITK'))
 _NO_DUAL = bool(os.environ.get('W2C_NO_DUAL'))
@@ -46,8 +44,6 @@ _FP8_SERIAL = bool(os.environ.get('W2C_FP8_SERIAL'))
 _NO_TAIL_OVERLAP = bool(os.environ.get('W2C_NO_TAIL_OVERLAP'))
 _HEAD_MFMA = os.environ.get('W2C_HEAD_MFMA', '1') != '0'   # fc.0 of the heads on the f32 matrix pipe (split-K partials)
 _GATE_U = os.environ.get('W2C_GATE_U', '1') != '0'         # the decoder's value-map conv waits for the policy chain's conv2
-_VALUE_LDS_KB = int(os.environ.get('W2C_VALUE_LDS_KB', '0'))   # A/B: LDS request of the value chain's conv launches (84: never two of them on one CU)
-_POLICY_LDS_KB = int(os.environ.get('W2C_POLICY_LDS_KB', '0'))  # (control: the same for the policy chain)
 _GRAPH_IO = os.environ.get('W2C_GRAPH_IO', '1') != '0'     # the stem and the upsample inside the captured graph (pointer slots)
 
 
@@ -329,21 +325,9 @@ class TrunkPlan:
         _stamp(0)
         side.wait_stream(main)
 
-        lag_ev = None
-
+        # (Measured and not kept, profiles/r04_s2_front_c64.txt + DESIGN 10: starting the value chain behind block k of the policy chain,
+        # and capping the value chain's workgroups per CU through its LDS request -- both lengthen the forward.)
         def chain(g):
-            pad = _VALUE_LDS_KB if g == 0 else _POLICY_LDS_KB
-            if not pad:
-                return chain_body(g)
-            from . import _native
-            old_pad = _native.set_option("W2C_LDS_PAD_KB", pad)
-            try:
-                return chain_body(g)
-            finally:
-                _native.set_option("W2C_LDS_PAD_KB", old_pad)
-
-        def chain_body(g):
-            nonlocal lag_ev
             _stamp(1 + g)
             q, off = p, g * cin0
             for bi, (c1, c2, ds) in enumerate(plans[g][0]):
@@ -353,9 +337,6 @@ class TrunkPlan:
                     t, idt = _block_front(c1, ds, q, x_ch_off=off)   # the chain's first block is a stride-2 block: idt is its own
                 q, off = c2.run(t, residual=idt), 0
                 _stamp(8 + 8 * g + bi)
-                if g == 1 and _VALUE_LAG and bi == _VALUE_LAG - 1:
-                    lag_ev = torch.cuda.Event()
-                    lag_ev.record(torch.cuda.current_stream(p.device))
             if squeezer_out is not None:
                 plans[g][1].run(q, out_groups=[squeezer_out[g]])
             else:
@@ -367,8 +348,6 @@ class TrunkPlan:
             chain(1)
             if policy_next is not None:            # the policy chain goes straight on (policy convs) beside the value chain
                 state = policy_next[0](sq if squeezer_out is None else squeezer_out[1])
-        if lag_ev is not None:                     # W2C_VALUE_LAG=k (A/B): the value chain starts behind the policy chain's block k
-            main.wait_event(lag_ev)
         chain(0)
         vres = value_next(sq if squeezer_out is None else squeezer_out[0]) if value_next is not None else None
         _stamp(26)
@@ -582,7 +561,9 @@ class DecoderPlan:
         """linear_fuse (CommEngine): the decoder's first conv runs on every agent's VALUE map before the fusion (it is linear before
         its bias, and so is the fusion: conv0(sum_k P V_k) = sum_k P conv0_nobias(V_k), csrc/comm_attn.hip graph_fuse_u_kernel) --
         `cu` = conv0 without bias / ReLU, f32 out; a decoder fed cat(fused, own) (MIMOcomWho, agent.py:1382) gets the two halves of
-        its filters as 2 x Cout output channels of one conv over V: [U | U_own]."""
+        its filters as TWO convs over V, U and U_own (round 5: two launches of Cout channels instead of one of 2 Cout, so that an
+        agent-parallel rank can write -- and all-gather -- U alone while U_own stays local; both paths run the same two convs, so a
+        shard still rounds like the unsharded batch: the split-K plan of a conv depends on its Cout)."""
         pred = decoder.output_decoder.pred
         self.c0 = ConvPlan([pred[0]], relu=True, in_perm=in_perm)
         self.c2 = ConvPlan([pred[2]], relu=False, pad_cout_to=32)
@@ -593,18 +574,35 @@ class DecoderPlan:
             cout, cin2 = w.shape[0], w.shape[1]
             feat = 512
             halves = cin2 // feat                                   # 1 (MIMOcom) or 2 (MIMOcomWho)
-            conv = torch.nn.Conv2d(feat, cout * halves, 3, padding=1, bias=False).to(w.device)
-            with torch.no_grad():
-                conv.weight.copy_(torch.cat([w[:, i * feat:(i + 1) * feat] for i in range(halves)], 0))
-            self.cu = ConvPlan([conv], relu=False)
-            self.cu.wfrag = None                                    # f32 output: the ring kernels' epilogue
+            self.cu_parts = []
+            for i in range(halves):
+                conv = torch.nn.Conv2d(feat, cout, 3, padding=1, bias=False).to(w.device)
+                with torch.no_grad():
+                    conv.weight.copy_(w[:, i * feat:(i + 1) * feat])
+                part = ConvPlan([conv], relu=False)
+                part.wfrag = None                                   # f32 output: the ring kernels' epilogue
+                self.cu_parts.append(part)
+            self.cu = self.cu_parts[0]
             self.cu_bias = pred[0].bias.detach().float().contiguous()
             self.c_hidden = cout
             self.own_off = cout if halves == 2 else -1
 
-    def value_maps(self, v, v_ch_off=0, out=None):
-        """U = conv0 without bias of the value maps v (bf16 NHWC, channels [v_ch_off, +512)) -> f32 NHWC [M,h,w,Cout | 2 Cout]"""
-        return self.cu.run(v, x_ch_off=v_ch_off, out_f32=True, out=out)
+    def value_maps(self, v, v_ch_off=0, out=None, out_own=None):
+        """U = conv0 without bias of the value maps v (bf16 NHWC, channels [v_ch_off, +512)) -> f32 NHWC [M,h,w,Cout] (MIMOcom), or
+        [M,h,w,2 Cout] = [U | U_own] (MIMOcomWho, one GPU); with out_own (MIMOcomWho, agent-parallel): U -> out [M,h,w,Cout] (this
+        rank's rows of the all-gather buffer), U_own -> out_own [M,h,w,Cout] (stays on the rank)."""
+        if len(self.cu_parts) == 1:
+            return self.cu.run(v, x_ch_off=v_ch_off, out_f32=True, out=out)
+        c = self.c_hidden
+        if out_own is not None:
+            self.cu_parts[0].run(v, x_ch_off=v_ch_off, out_f32=True, out=out)
+            self.cu_parts[1].run(v, x_ch_off=v_ch_off, out_f32=True, out=out_own)
+            return out
+        if out is None:
+            out = torch.empty((v.shape[0], v.shape[1], v.shape[2], 2 * c), dtype=torch.float32, device=v.device)
+        self.cu_parts[0].run(v, x_ch_off=v_ch_off, out_f32=True, out=out, out_ch_off=0)
+        self.cu_parts[1].run(v, x_ch_off=v_ch_off, out_f32=True, out=out, out_ch_off=c)
+        return out
 
     def low_logits(self, feat):
         y = self.c0.run(feat)
@@ -684,13 +682,13 @@ class CommEngine:
         DecoderPlan.value_maps), projected keys f32 [n*B,Dq+1], queries f32 [n*B,Dq] or None."""
         return self.encode_from_stem(self.trunk.stem(x, n_agents))
 
-    def value_maps(self, v_src, out=None):
+    def value_maps(self, v_src, out=None, out_own=None):
         """U maps of the value maps in channels [0, feat) of v_src (the 2-trunk squeezer tensor or a V-only tensor); behind the
         policy chain's conv2 when policy_convs(gate=True) ran before it in this forward"""
         if self.__dict__.get("_gate_armed"):
             self._gate_armed = False
             torch.cuda.current_stream(v_src.device).wait_event(self._ev_conv2)
-        return self.decoder.value_maps(v_src, 0, out=out)
+        return self.decoder.value_maps(v_src, 0, out=out, out_own=out_own)
 
     def encode_from_stem(self, s0):
         """Everything between the pooled stem output and the communication graph -> (sq, u, tproj, queries).
@@ -707,36 +705,35 @@ class CommEngine:
         # a process delivered a few wrong fc.0 outputs in 5 of 8 processes.  The cause was found later -- packed-f32 FMAs of the head
         # kernel beside the value chain's MFMA waves; the library is built without them now (and the build FAILS if
         # they come back: _build.check_no_packed_f32), and tools/stress_first_forward.py reports 0 of 29 first forwards differing in
-        # this form.  W2C_HEADS_AFTER_JOIN=1 restores the old one.
+        # this form.
         # Round 4: the VALUE chain carries on too -- the decoder's first conv on every agent's value map (by linearity), in the
         # ~100 us that chain used to idle before the join.
-        if not _HEADS_AFTER_JOIN:
-            def tail(s):
-                y = self.policy_convs(s, gate=_GATE_U)
-                _stamp(6)
-                r = self.policy_heads(y)
-                _stamp(7)
-                return r
-            sq, (keys, querys), u = self.trunk.after_stem(s0, policy_next=(tail, lambda r: r), value_next=self.value_maps)
-            return sq, u, keys, querys
-        sq, (keys, querys), u = self.trunk.after_stem(s0, policy_next=(self.policy_convs, self.policy_heads), value_next=self.value_maps)
+        def tail(s):
+            y = self.policy_convs(s, gate=_GATE_U)
+            _stamp(6)
+            r = self.policy_heads(y)
+            _stamp(7)
+            return r
+        sq, (keys, querys), u = self.trunk.after_stem(s0, policy_next=(tail, lambda r: r), value_next=self.value_maps)
         return sq, u, keys, querys
 
-    def graph_and_low(self, u_all, keys_all, querys_local, B, N, q_lo, q_n, mode, pack2=None):
+    def graph_and_low(self, u_all, keys_all, querys_local, B, N, q_lo, q_n, mode, pack2=None, u_own=None):
         """Communication graph for local query agents [q_lo, q_lo+q_n) over all N keys, fusion of the agents' U maps (+ bias + ReLU
         = the decoder's first layer), the decoder's last conv: everything up to the low-resolution logits.
-        u_all: f32 NHWC [N*B,h,w,C | 2C] from value_maps (rows of agents whose coefficient is 0 for every local query are not read)."""
+        u_all: f32 NHWC [N*B,h,w,C | 2C] from value_maps (rows of agents whose coefficient is 0 for every local query are not read).
+        u_own (MIMOcomWho, agent-parallel): the local queries' U_own maps [q_n*B,h,w,C]; default: channels [C, 2C) of u_all's rows."""
         d = self.decoder
         y, prob, _, action, nnz, pack = ops.comm_graph_fuse_u(querys_local, keys_all, u_all, d.c_hidden, d.cu_bias, B, N, self.who, mode,
-                                                              q_lo=q_lo, q_n=q_n, own_off=d.own_off, pack2=pack2)
+                                                              q_lo=q_lo, q_n=q_n, own_off=-1 if u_own is not None else d.own_off,
+                                                              pack2=pack2, u_own=u_own)
         self._last_pack = pack             # prob / action / nnz are views of this one buffer (ops.graph_outputs)
         _stamp(24)
         low = d.c2.run(y, out_f32=True)
         _stamp(25)
         return low, prob, action, nnz
 
-    def graph_and_decode(self, u_all, keys_all, querys_local, B, N, q_lo, q_n, mode):
-        low, prob, action, nnz = self.graph_and_low(u_all, keys_all, querys_local, B, N, q_lo, q_n, mode)
+    def graph_and_decode(self, u_all, keys_all, querys_local, B, N, q_lo, q_n, mode, u_own=None):
+        low, prob, action, nnz = self.graph_and_low(u_all, keys_all, querys_local, B, N, q_lo, q_n, mode, u_own=u_own)
         return ops.upsample_bilinear32(low, self.n_classes), prob, action, nnz, low
 
     def _confusion_ws(self, dev):

@@ -1144,9 +1144,12 @@ def pack_offsets(B, N, q_n):
     return off_act, off_act + n_act
 
 
-def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None, own_off=-1, pack2=None):
+def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_bias=0.001, q_lo=0, q_n=None, own_off=-1, pack2=None,
+                      u_own=None):
     """w2c_comm_graph_fuse_u: graph + fusion of the U maps (decoder conv0 of every agent's value map, no bias, f32 NHWC
     [N*B,h,w,ucs]) + bias + ReLU -> y bf16 [q_n*B,h,w,C] = relu(conv0(fused map)), prob, coef, action, nnz, pack.
+    MIMOcomWho's own term: u_own = f32 [q_n*B,h,w,own_cs] rows of the LOCAL queries (channels [0,C)), or own_off >= 0 = the own map sits
+    in channels [own_off, own_off+C) of u's own rows (the one-GPU layout [U | U_own]).
     pack2: optional tensor / SlotRef receiving a second copy of the packed prob | action | nnz (the caller-owned outputs of a
     captured forward)."""
     dev = _need_gpu(query, tproj, u, bias)
@@ -1158,11 +1161,21 @@ def comm_graph_fuse_u(query, tproj, u, C, bias, B, N, who, mode, thres=0.2, tie_
     pack, prob, action, nnz = graph_outputs(dev, B, N, q_n)
     coef = torch.empty((B, N, q_n), dtype=torch.float32, device=dev)
     _, h, w, ucs = u.shape
+    own_ptr, own_cs = 0, 0
+    if u_own is not None:
+        if (u_own.dtype != torch.float32 or u_own.device != dev or u_own.dim() != 4 or u_own.shape[0] != q_n * B or tuple(u_own.shape[1:3]) != (h, w)
+                or u_own.shape[3] < C or not u_own.is_contiguous()):
+            raise W2CError("comm_graph_fuse_u: u_own must be contiguous f32 [q_n*B,h,w,>=C] on u's device")
+        own_ptr, own_cs = u_own.data_ptr(), u_own.shape[3]
+    elif own_off >= 0:
+        if own_off + C > ucs:
+            raise W2CError("comm_graph_fuse_u: own_off + C exceeds u's channel stride")
+        own_ptr, own_cs = u.data_ptr() + 4 * (q_lo * B * h * w * ucs + own_off), ucs
     out = torch.empty((q_n * B, h, w, C), dtype=BF16, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_comm_graph_fuse_u(_p(query), _p(tproj), B, N, Dq, 1 if who else 0, MODE_IDS[mode], float(thres),
                                                   float(tie_bias), q_lo, q_n, _p(prob), _p(coef), _p(action), _p(nnz), _p(u), ucs,
-                                                  h * w, C, int(own_off), _p(bias), _p(out), C, _p(pack2), *pack_offsets(B, N, q_n),
+                                                  h * w, C, own_ptr or None, own_cs, _p(bias), _p(out), C, _p(pack2), *pack_offsets(B, N, q_n),
                                                   _stream(dev)),
               "w2c_comm_graph_fuse_u")
     return out, prob, coef, action, nnz, pack

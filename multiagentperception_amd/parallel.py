@@ -100,8 +100,9 @@ def sparse_exchange(v_local, need, B, N, group=None):
     return v_all, len(flat_recv), (world - 1) * n_loc * B
 
 
-# ProcessGroupNCCL's flight recorder is how _watchdog_idle() SEES the watchdog's list (see there).  Its ring buffer must exist when the
-# process group is created; recent PyTorch enables it by default, older builds read this variable.
+# ProcessGroupNCCL's flight recorder is how _watchdog_idle() SEES the watchdog's list (see there).  Its ring buffer is sized when the
+# process group is created (default 0 = off in torch 2.10): the package's __init__ sets the variable, bench.py sets it before importing
+# torch; a process that created its group before either gets the 3-segment form (and a warning), never an unproven capture.
 os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
 _WATCHDOG_IDLE_TIMEOUT_S = float(os.environ.get("W2C_WATCHDOG_IDLE_TIMEOUT_S", "20"))
 
@@ -206,11 +207,13 @@ class _ShardState:
         self.s0 = torch.empty((n_loc * B, H // 4, W // 4, 64 * eng.trunk.G), dtype=bf16, device=dev)   # pooled stem output
         # What crosses the wire per agent-sample is U = the decoder's first conv of the value map (f32, 256 channels: the same 1 KiB
         # per pixel as the bf16 512-channel V it replaces; engine.DecoderPlan.value_maps -- conv0 is linear before its bias, and so is
-        # the fusion).  MIMOcomWho: [U | U_own], 2 KiB per pixel (only the first half is used by the peers).
+        # the fusion).  MIMOcomWho's second map U_own (the conv of V[q] with the other half of conv0's filters, used by the agent's OWN
+        # decode only) never leaves the rank (round 5; round 4 gathered [U | U_own]: twice the xGMI bytes the model needs).
         d = eng.decoder
-        ucs = d.c_hidden * (2 if d.own_off >= 0 else 1)
+        ucs = d.c_hidden
         self.v_loc = torch.empty((n_loc * B, h, w, eng.feat), dtype=bf16, device=dev)   # local value maps (the value trunk's squeezer)
         self.v_all = torch.zeros((N * B, h, w, ucs), dtype=torch.float32, device=dev)   # every agent's U map
+        self.u_own = torch.zeros((n_loc * B, h, w, ucs), dtype=torch.float32, device=dev) if d.own_off >= 0 else None
         self.pol = torch.empty((n_loc * B, h, w, eng.feat), dtype=bf16, device=dev)     # local policy-encoder map
         dq = eng.wq.shape[1]
         self.k_all = torch.zeros((N * B, dq + 1), dtype=torch.float32, device=dev)      # projected keys of every agent
@@ -321,7 +324,7 @@ class AgentParallelForward:
             exchange_wait(v_work)
             exchange_wait(k_work)
             low, prob, action, nnz = st.run(
-                "C:softmax", lambda: eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, "softmax"),
+                "C:softmax", lambda: eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, "softmax", u_own=st.u_own),
                 use_graph)
             pred = ops.upsample_bilinear32(low, eng.n_classes)
         if use_graph:
@@ -338,7 +341,7 @@ class AgentParallelForward:
         if _SPARSE_FORCE is not None:
             return _SPARSE_FORCE
         B, _, H, W = x.shape
-        ucs = 512 if eng.who else 256
+        ucs = 256                                           # U alone crosses the links (MIMOcomWho's U_own stays on the rank)
         recv = (self.world - 1) * self.n_loc * B * (H // 32) * (W // 32) * ucs * 4
         return recv >= _SPARSE_MIN_BYTES
 
@@ -381,7 +384,7 @@ class AgentParallelForward:
                     # U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K gather
                     # (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel under
                     # the policy tail.  The K gather is issued from the policy chain's stream, behind the heads.
-                    u = eng.value_maps(v, out=st.v_slot)
+                    u = eng.value_maps(v, out=st.v_slot, out_own=st.u_own)
                     works.append(_gather_inplace(st.v_all, self.rank, rows, self.group))
                     if done.get("heads"):
                         with torch.cuda.stream(pol_stream):
@@ -400,7 +403,7 @@ class AgentParallelForward:
                 for wk in works:
                     exchange_wait(wk)
                 pack2 = ops.SlotRef(slots, 2, ops.graph_outputs(dev, B, N, n_loc)[0])
-                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=pack2)
+                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=pack2, u_own=st.u_own)
                 pack = eng._last_pack
                 ops.upsample_bilinear32(low, eng.n_classes, out=outs)
                 return pack
@@ -482,14 +485,14 @@ class AgentParallelForward:
             eng.trunk.calibrate(st.s0, reduce_amax=_max_over_ranks)
         if eng.trunk.n8:
             st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol],
-                                                      value_next=lambda v: eng.value_maps(v, out=st.v_slot))[2],), use_graph)
+                                                      value_next=lambda v: eng.value_maps(v, out=st.v_slot, out_own=st.u_own))[2],), use_graph)
             st.pol_y = None
         else:
             # as in the one-GPU forward, policy conv1..5 ride the policy chain's stream beside the value chain (they were the whole of
             # the sharded path's extra 0.09 ms per step when segment B ran them after the join); segment B keeps the heads
             a = st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol],
                                                           policy_next=(lambda pol: eng.policy_convs(pol, ch_off=0, gate=True), lambda y: y),
-                                                          value_next=lambda v: eng.value_maps(v, out=st.v_slot))[1],),
+                                                          value_next=lambda v: eng.value_maps(v, out=st.v_slot, out_own=st.u_own))[1],),
                        use_graph)
             st.pol_y = a[0]
         return st
@@ -515,7 +518,7 @@ class AgentParallelForward:
         need = (coef_full != 0).cpu()                                          # the handshake's one host round trip
         v_all, got, dense = sparse_exchange(st.v_slot, need, B, N, self.group)
         self.last_exchange = (got, dense)
-        pred, prob, action, nnz, _ = eng.graph_and_decode(v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, inference)
+        pred, prob, action, nnz, _ = eng.graph_and_decode(v_all, st.k_all, st.q_loc, B, N, self.q_lo, self.n_loc, inference, u_own=st.u_own)
         return pred, prob, action, nnz
 
 

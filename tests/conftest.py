@@ -26,6 +26,12 @@ def pytest_sessionstart(session):
         import torch
         if torch.cuda.is_available():
             from multiagentperception_amd import _native
-            _native.lib().w2c_debug_install_crash_backtrace()
+            fd = 2
+            try:                                 # pytest captures fd 2; the faulthandler plugin kept a dup of the real stderr
+                from _pytest.faulthandler import fault_handler_stderr_fd_key
+                fd = int(session.config.stash[fault_handler_stderr_fd_key])
+            except Exception:
+                pass
+            _native.lib().w2c_debug_install_crash_backtrace(fd)
     except Exception as e:                      # a debug aid must never take the suite down
         print("conftest: crash backtrace handler not installed (%r)" % (e,))

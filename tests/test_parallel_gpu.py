@@ -129,7 +129,9 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    # (TORCH_FR_BUFFER_SIZE removed: bench.py must switch the flight recorder on by itself, before it creates the process group --
+    #  the one-graph step refuses to capture collectives it cannot prove safe, parallel._watchdog_idle)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCH_FR_BUFFER_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-sharded", "--batch", "2", "--size", "128",
                         "--steps", "5", "--warmup", "2", "--no-pmc"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=900)
@@ -138,7 +140,7 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
     assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines[-3:]   # ONE JSON line (RCCL's banner goes to stderr)
     d = json.loads(out_lines[0])
     # round 4: with the nccl backend the rank's whole step -- collectives included -- is ONE captured graph (parallel._softmax_one_graph)
-    assert d["n_gpus"] == 1 and ("one hip-graph" in d["config"]["launch"] or "segments" in d["config"]["launch"]), d["config"]["launch"]
+    assert d["n_gpus"] == 1 and "one hip-graph" in d["config"]["launch"], (d["config"]["launch"], r.stderr.decode()[-1500:])
     assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
 
 

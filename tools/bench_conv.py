@@ -43,9 +43,8 @@ VALID = {  # variant -> (BM, BN, BK)
     0: (128, 128, 64), 3: (128, 64, 64), 6: (64, 64, 64), 8: (128, 32, 64),
     30: (128, 128, 64), 36: (128, 64, 64), 38: (128, 64, 64), 50: (64, 64, 64), 52: (64, 64, 64), 54: (128, 64, 64),
     80: (128, 128, 64), 81: (128, 64, 64), 83: (128, 64, 64), 93: (128, 64, 64), 94: (128, 64, 64),      # conv_wreg.inl forms
-    95: (128, 64, 64), 96: (128, 64, 64),                                                                # ... 32 channels per wave
 }
-PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 52: (4, 16), 54: (8, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16), 95: (8, 16), 96: (8, 16)}
+PATCH_GEOM = {30: (8, 16), 36: (8, 16), 38: (8, 16), 50: (4, 16), 52: (4, 16), 54: (8, 16), 80: (8, 16), 81: (8, 16), 83: (8, 16), 93: (8, 16), 94: (8, 16)}
 
 
 def main():

@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256) void mfma_hog(float* sink, int iters) {
 }
 
 // MEM: the multiplier pairs come from global memory (16 B per lane and step, two slices in flight), as in linear_widek_kernel
-template <bool MEM>
+// SEL (round 5): the operand-select forms the SLP-packed build of linear_widek_kernel actually contains (tools/r05: its ISA has 120
+// v_pk_fma_f32, every one with a broadcast of ONE multiplier dword to both halves): 0 = plain, 1 = op_sel_hi:[1,0,1] (both halves read
+// src1's LOW dword), 2 = op_sel:[0,1,0] (both halves read src1's HIGH dword -- the low half crosses over).
+template <bool MEM, int SEL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pk_checker(const float* __restrict__ w, int steps,
                                                                                              unsigned long long* bad, float* sink) {
     const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -57,9 +60,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < 4; ++r) {
             const f32x2_t xv = {x0 + 0.125f * r, x1 - 0.0625f * r};
             const f32x2_t wv = {w4[r], w4[(r + 1) & 3]};
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(accp[r]) : "v"(xv), "v"(wv));
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(accs[r][0]) : "v"(xv[0]), "v"(wv[0]));
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(accs[r][1]) : "v"(xv[1]), "v"(wv[1]));
+            if (SEL == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(accp[r]) : "v"(xv), "v"(wv));
+            if (SEL == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(accp[r]) : "v"(xv), "v"(wv));
+            if (SEL == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(accp[r]) : "v"(xv), "v"(wv));
+            const float m0 = SEL == 2 ? wv[1] : wv[0], m1 = SEL == 1 ? wv[0] : wv[1];
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(accs[r][0]) : "v"(xv[0]), "v"(m0));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(accs[r][1]) : "v"(xv[1]), "v"(m1));
         }
         x0 = x0 * 0.99951171875f + 4.8828125e-4f;
         x1 = x1 * 1.00048828125f - 2.44140625e-4f;
@@ -76,14 +82,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <bool MEM>
+template <bool MEM, int SEL = 0>
 static void run(const char* name, int hog, hipStream_t s_chk, hipStream_t s_hog, const float* w, unsigned long long* bad, float* sink) {
     CK(hipMemset(bad, 0, 16));
     const int rounds = 40;
     for (int r = 0; r < rounds; ++r) {
         if (hog == 1) hipLaunchKernelGGL(mfma_hog<true>, dim3(512), dim3(256), 0, s_hog, sink, 400);      // 2 workgroups per CU: 8 waves, 2 per SIMD
         if (hog == 2) hipLaunchKernelGGL(mfma_hog<false>, dim3(512), dim3(256), 0, s_hog, sink, 400);
-        for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(pk_checker<MEM>, dim3(512), dim3(256), 0, s_chk, w, 3000, bad, sink);
+        for (int k = 0; k < 4; ++k) hipLaunchKernelGGL((pk_checker<MEM, SEL>), dim3(512), dim3(256), 0, s_chk, w, 3000, bad, sink);
     }
     CK(hipDeviceSynchronize());
     unsigned long long h[2];
@@ -110,5 +116,12 @@ int main() {
     run<true>("operands from global memory, alone", 0, s0, s1, w, bad, sink);
     run<true>("operands from global memory, beside MFMA (AGPR acc.)", 1, s0, s1, w, bad, sink);
     run<true>("operands from global memory, beside MFMA (VGPR acc.)", 2, s0, s1, w, bad, sink);
+    run<true, 1>("global operands, op_sel_hi:[1,0,1] (low dword to both), alone", 0, s0, s1, w, bad, sink);
+    run<true, 1>("global operands, op_sel_hi:[1,0,1], beside MFMA (AGPR acc.)", 1, s0, s1, w, bad, sink);
+    run<true, 1>("global operands, op_sel_hi:[1,0,1], beside MFMA (VGPR acc.)", 2, s0, s1, w, bad, sink);
+    run<true, 2>("global operands, op_sel:[0,1,0] (high dword to both), alone", 0, s0, s1, w, bad, sink);
+    run<true, 2>("global operands, op_sel:[0,1,0], beside MFMA (AGPR acc.)", 1, s0, s1, w, bad, sink);
+    run<true, 2>("global operands, op_sel:[0,1,0], beside MFMA (VGPR acc.)", 2, s0, s1, w, bad, sink);
+    run<false, 2>("register operands, op_sel:[0,1,0], beside MFMA (AGPR acc.)", 1, s0, s1, w, bad, sink);
     return 0;
 }
