@@ -345,6 +345,8 @@ class TrunkPlan:
 
         state = None
         with torch.cuda.stream(side):
+            # (Measured and not kept, profiles/r05_policy_tail.txt: the policy chain's conv launches at s_setprio 3 -- it is the critical
+            # path, the value chain has ~100 us of slack -- make BOTH chains slower: 0.992-0.999 -> 1.010-1.016 ms.)
             chain(1)
             if policy_next is not None:            # the policy chain goes straight on (policy convs) beside the value chain
                 state = policy_next[0](sq if squeezer_out is None else squeezer_out[1])
@@ -1003,20 +1005,28 @@ class SRMSEngine:
         sq = self.trunk.run(x, N)                                       # [5B,h,w,1024]: V | policy map
         pol_off = self.feat
         if getattr(self, "trunks5", None) is not None:                  # sq = the policy map alone [5B,h,w,512]
-            # five separate value encoders: five independent single-trunk chains -> five parallel branches (forked streams) instead of
-            # five chains one after the other
+            # five separate value encoders: five independent single-trunk chains, forked over TWO side streams (encoder i on stream i % 2)
+            # beside the policy encoder's chain on the main stream -- three parallel branches, not six.  Why not one stream each (round 4):
+            # hipGraphLaunch picks the graph's branch streams from the max_streams the exec created at instantiate, SKIPPING those that
+            # share the launch stream's hardware queue, without a bounds check (libamdhip64 of ROCm 7.0: the loop at GraphExec's
+            # UpdateStreams reads past the vector when more than ONE of them collides) -- with the default 4 hardware queues a graph of
+            # >= 5 parallel branches can always draw two collisions, and the out-of-bounds pointer is what segfaulted the replay of exactly
+            # this graph in GPUTEST_r04 and again in round 5 (profiles/r05_capture_crash.txt: native frames + disassembly).  <= 4 branches
+            # cannot overrun under round-robin queue assignment; every graph of this package now has <= 3.
             main = torch.cuda.current_stream(x.device)
-            parts = []
-            for i, t in enumerate(self.trunks5):
-                st = self.trunk._side_stream(x.device, 2 + i)
+            parts = [None] * len(self.trunks5)
+            sides = [self.trunk._side_stream(x.device, 2 + k) for k in range(2)]
+            for st in sides:
                 st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    parts.append(t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1))
+            for i, t in enumerate(self.trunks5):
+                with torch.cuda.stream(sides[i % 2]):
+                    parts[i] = t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1)
             capturing = torch.cuda.is_current_stream_capturing()
-            for i in range(len(self.trunks5)):
-                main.wait_stream(self.trunk._side_stream(x.device, 2 + i))
-                if not capturing:                   # eager: the block was allocated on the side stream and is consumed on main.  Inside a
-                    parts[i].record_stream(main)    # capture the graph's own edges order producer, consumer and any reuse of the block
+            for st in sides:
+                main.wait_stream(st)
+            if not capturing:                       # eager: the blocks were allocated on a side stream and are consumed on main.  Inside a
+                for pt in parts:                    # capture the graph's own edges order producer, consumer and any reuse of the block
+                    pt.record_stream(main)
             vcs_src = torch.cat(parts, 0)
             pol_off = 0
         elif self.trunk0 is not None:
