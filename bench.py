@@ -49,6 +49,8 @@ import numpy as np
 # ProcessGroupNCCL's flight recorder must exist when the process group is created: the sharded one-graph step proves the watchdog's list empty
 # through it before it captures collectives (multiagentperception_amd/parallel.py _watchdog_idle); without it the step takes the 3-segment form
 os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
+# 16 hardware queues: the mitigation of the hipGraphLaunch out-of-bounds read (multiagentperception_amd/__init__.py); read when HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -85,3 +85,29 @@ def test_no_capture_site_bypasses_the_guard():
                 if re.search(r"torch\.cuda\.graph\(", line) and not line.lstrip().startswith(("#", '"', "'")):
                     hits.append((fn, i))
     assert hits and all(fn == "ops.py" for fn, _ in hits), hits
+
+
+def _repro(queues, iters="400", branches="3"):
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(queues))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r05", "hipgraph_oob_repro.py"), iters, branches],
+                          capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_graph_launches_survive_bursts_of_exec_destruction_with_the_packages_queue_count():
+    """The crash of GPUTEST_r04 (profiles/r05_capture_crash.txt): hipGraphLaunch skips the exec streams that share the launch stream's hardware
+    queue without a bounds check; at the runtime's default of 4 hardware queues a burst of exec destructions makes the next execs' streams
+    pile onto one queue and a launch from a stream on that queue reads past the vector.  tools/r05/hipgraph_oob_repro.py is that pattern in
+    pure torch (4 instantiations, 3 dropped, replays from 3-7 long-lived streams, 6 000 launches here).  With the queue count this package
+    sets before the runtime initialises (GPU_MAX_HW_QUEUES=16: package __init__, bench.py, tests/conftest.py) it must survive."""
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "16"
+    r = _repro(16)
+    assert r.returncode == 0 and "SURVIVED" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_the_runtime_defect_is_real_at_the_default_queue_count():
+    """Documents the defect on this stack: the same script at GPU_MAX_HW_QUEUES=4 (the runtime's default) dies with SIGSEGV inside
+    libamdhip64's hipGraphLaunch within a few hundred launches.  A later runtime that survives makes the mitigation unnecessary, not wrong."""
+    r = _repro(4)
+    if r.returncode == 0:
+        pytest.skip("this HIP runtime survives the pattern at 4 hardware queues")
+    assert r.returncode < 0, (r.returncode, r.stderr[-1500:])
