@@ -811,14 +811,15 @@ class CommEngine:
         return out, prob, action, nnz
 
     def _audition(self, x, B, N, mode, labels, confusion, out):
-        """Capture the forward W2C_GRAPH_AUDITION (4) times and keep the instantiation that replays fastest.  Why: how a graph's parallel
-        branches land on the runtime's streams / hardware queues is decided per instantiation, and a bad assignment replays the SAME
-        graph slower for its whole life -- 2-3x when dependent launches sit on different queues (every edge a cross-queue signal), ~1.35x
-        when the two trunk chains share one (tools/graph_audition.py: with GPU_MAX_HW_QUEUES=5 the first two captures of a process run
-        at 2.0-2.1 ms, the later ones at 1.10; with the default 4 about 2 % of fresh processes drew the bad one: the 2.97 ms state
-        bench.py guards against).  Consecutive instantiations cycle through the assignments, so a few candidates see them all; no
-        early exit (two slow candidates in a row agree with each other, too).  Costs ~0.15 s at the first forward of a shape.
-        W2C_GRAPH_AUDITION=1: take the first capture as it comes.  self.audition_ms = the candidates' replay times."""
+        """Capture the forward W2C_GRAPH_AUDITION (4) times and keep the instantiation that replays fastest.  Why: which runtime streams --
+        hardware queues, and behind them the command processor's pipes -- a graph's parallel branches land on is decided per instantiation,
+        and when the two trunk chains land on one pipe they do not overlap: the SAME graph replays ~1.7x slower for its whole life.  Round
+        5, 18 fresh processes (gpurun_out/r05_p): at the 16 hardware queues the package runs with (see the package's __init__: the
+        hipGraphLaunch out-of-bounds read) every OTHER instantiation is in that state -- candidates 2.0 / 1.19 / 2.0 / 1.19 ms --, at the
+        runtime's default 4 queues about 2 % of fresh processes drew it (round 4).  Consecutive instantiations cycle through the
+        assignments, so a few candidates see a good one; no early exit.  Costs ~0.15 s at the first forward of a shape.
+        W2C_GRAPH_AUDITION=1: take the first capture as it comes.  self.audition_ms = the candidates' replay times.
+        (ops.capture_best is the same thing for the graphs without pointer slots: the single-request engines, the sharded segment A.)"""
         dev = x.device
         gt, hist = confusion if confusion is not None else (None, None)
         scratch_hist = None if hist is None else torch.zeros_like(hist)
@@ -991,8 +992,9 @@ class SRMSEngine:
                     self._forward(xs, mode, out=outs)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            with ops.capture() as graph:
-                res = self._forward(xs, mode, out=outs)
+            # (the five-encoder variant has three parallel branches, the others two: which runtime streams they land on is decided per
+            # instantiation -- ops.capture_best keeps the one that replays fastest, as CommEngine._audition does)
+            graph, res, self.audition_ms = ops.capture_best(lambda: self._forward(xs, mode, out=outs), _GRAPH_AUDITION)
             ent = graphs[key] = (graph, xs, slots, res[1:])
         graph, xs, slots, small = ent
         xs.copy_(x, non_blocking=True)

@@ -242,8 +242,9 @@ class _ShardState:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             from . import ops
-            with ops.capture() as g:
-                res = fn()
+            from .engine import _GRAPH_AUDITION
+            # segment A holds the two trunk chains: auditioned like the one-GPU forward (ops.capture_best); B and C are single chains
+            g, res, _ = ops.capture_best(fn, _GRAPH_AUDITION if name == "A" else 1)
             self.graphs[name] = (g, res)
             g = self.graphs[name]
         g[0].replay()
