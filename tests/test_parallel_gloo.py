@@ -183,3 +183,56 @@ def test_inplace_gather_of_preplaced_shards(tmp_path):
         d = torch.load(os.path.join(str(tmp_path), "ip%d.pt" % r))
         np.testing.assert_array_equal(d["buf"].numpy(), want.numpy())
         np.testing.assert_array_equal(d["kbuf"].numpy(), wantk.numpy())
+
+
+def _loss_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import functools
+    from multiagentperception_amd import parallel
+    from multiagentperception_amd.loss import cross_entropy2d, bootstrapped_cross_entropy2d
+    gen = torch.Generator().manual_seed(5)
+    logits = torch.randn(4, 11, 8, 8, generator=gen)
+    labels = torch.randint(0, 11, (4, 8, 8), generator=gen)
+    labels[0, :6] = 250                                    # most of rank 0's first image is ignored: the ranks' denominators differ
+    weight = torch.rand(11, generator=gen) + 0.5
+    lo, hi = rank * 2, rank * 2 + 2
+    res = {}
+    for name, fn in (("plain", cross_entropy2d), ("weighted", functools.partial(cross_entropy2d, weight=weight)),
+                     ("boot", functools.partial(bootstrapped_cross_entropy2d, K=16))):
+        pred = logits[lo:hi].clone().requires_grad_(True)
+        term, glob = parallel._sharded_loss(fn, pred, labels[lo:hi], None)
+        term.backward()
+        res[name] = (float(glob), pred.grad.clone())
+    torch.save(res, os.path.join(out_dir, "loss%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_loss_uses_the_global_denominator(tmp_path):
+    """parallel._sharded_loss: the size-average cross entropy over a sharded batch is sum / GLOBAL denominator -- with ignored
+    pixels or class weights the mean of the ranks' means is not -- and each rank's gradient is its slice of the unsharded gradient; a loss
+    that is a mean over images of per-image terms (bootstrapped) keeps the mean of the ranks' values.  CPU tensors, gloo, world 2."""
+    import functools
+    from multiagentperception_amd.loss import cross_entropy2d, bootstrapped_cross_entropy2d
+    world = 2
+    mp.spawn(_loss_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "loss%d.pt" % r)) for r in range(world)]
+    gen = torch.Generator().manual_seed(5)
+    logits = torch.randn(4, 11, 8, 8, generator=gen)
+    labels = torch.randint(0, 11, (4, 8, 8), generator=gen)
+    labels[0, :6] = 250
+    weight = torch.rand(11, generator=gen) + 0.5
+    for name, fn in (("plain", cross_entropy2d), ("weighted", functools.partial(cross_entropy2d, weight=weight)),
+                     ("boot", functools.partial(bootstrapped_cross_entropy2d, K=16))):
+        x = logits.clone().requires_grad_(True)
+        ref = fn(x, labels)
+        ref.backward()
+        for r in range(world):
+            assert abs(got[r][name][0] - float(ref)) <= 1e-5 * abs(float(ref)), (name, got[r][name][0], float(ref))
+            np.testing.assert_allclose(got[r][name][1].numpy(), x.grad[2 * r:2 * r + 2].numpy(), rtol=1e-5, atol=1e-7)
+    # and the mean of the ranks' means would have been wrong for this batch
+    naive = 0.5 * (float(cross_entropy2d(logits[:2], labels[:2])) + float(cross_entropy2d(logits[2:], labels[2:])))
+    assert abs(naive - float(cross_entropy2d(logits, labels))) > 1e-3
