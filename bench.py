@@ -46,11 +46,6 @@ import time
 
 import numpy as np
 
-# ProcessGroupNCCL's flight recorder must exist when the process group is created: the sharded one-graph step proves the watchdog's list empty
-# through it before it captures collectives (multiagentperception_amd/parallel.py _watchdog_idle); without it the step takes the 3-segment form
-os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
-# 16 hardware queues: the mitigation of the hipGraphLaunch out-of-bounds read (multiagentperception_amd/__init__.py); read when HIP initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -78,6 +73,15 @@ def build_cfg(arch, agent_num, size, query=True):
                           sparse=False, query=query, query_size=32, key_size=1024, enc_backbone="resnet_encoder",
                           dec_backbone="simple_decoder", feat_squeezer=-1, feat_channel=512, multiple_output=True),
             "data": {"img_rows": size, "img_cols": size}}
+
+
+def _n_graphs(model, x, fwd):
+    """number of single-branch graphs in the recorded program the timed steps replayed (0 if none)"""
+    try:
+        eng = model._engine_for(x, fwd._engine_cls)
+        return max([e[0].n_graphs for e in eng._graphs.values()] + [0])
+    except Exception:                                        # noqa: BLE001
+        return 0
 
 
 def _free_port():
@@ -366,7 +370,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # first forward of the process: packs the weights, warms up and records the program (ops.record_program) -- reported as a side key
+    torch.cuda.synchronize(dev)
+    t_first = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize(dev)
+    first_forward_ms = 1e3 * (time.perf_counter() - t_first)
+    for _ in range(max(0, args.warmup - 1)):
         out = step()
     fence()
     marks = []
@@ -386,10 +396,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     launch_form = getattr(fwd, "launch_form", "")            # what the TIMED steps ran as (later legs may take other paths)
-    try:                                                     # replay times of the graph instantiations the engine auditioned (engine._audition)
-        audition_ms = getattr(fwd, "audition_ms", None) or getattr(model._engine_for(x, fwd._engine_cls), "audition_ms", None)
-    except Exception:                                        # noqa: BLE001
-        audition_ms = None
+    n_graphs = _n_graphs(model, x, fwd)
     images_per_step = B * N
     value = images_per_step * args.steps / elapsed
 
@@ -478,25 +485,19 @@ def main():
                   config=dict(workload=workload, preset=args.config, agents_total=N, agents_per_gpu=n_loc, global_batch=B,
                               frames_per_s=round(B * args.steps / elapsed, 2),
                               parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
-                              launch=("hip-graph replay" if (world == 1 and not args.force_sharded) else
-                                      ("sharded: " + launch_form if "one hip-graph" in launch_form
-                                       else "3 hip-graph segments + eager collectives"))
-                              if model.use_hip_graph else "eager"),
-                  roofline=roofline, host_enqueue=host_enqueue)
-    if audition_ms:
-        result["config"]["graph_audition_ms"] = audition_ms
+                              launch=(("recorded program: %d single-branch hip-graphs on 2 lanes + event edges" % n_graphs
+                                       if (world == 1 and not args.force_sharded) else "sharded: " + launch_form)
+                                      if model.use_hip_graph else "eager")),
+                  roofline=roofline, host_enqueue=host_enqueue,
+                  first_forward_ms=round(first_forward_ms, 1))
 
-    # ---- guard: the slow-replay state ----------------------------------------------------------------------------------------------
-    # Twice in ~90 fresh-process runs of round 4 (profiles/r04_rank_shapes.txt, first raw line of job r04_e; an A/B loop earlier) a process replayed
-    # its graph at ~2.97 ms per step WHATEVER the workload (cfg 2: 1.07 ms of kernels; a cfg-3 rank: 0.6), with the in-kernel launch
-    # spans at their usual length: the chip idles between launches.  Cause, found late in the round (tools/graph_audition.py,
-    # tools/ab_hwq.sh): how a graph instantiation's parallel branches land on the runtime's streams / hardware queues -- with
-    # GPU_MAX_HW_QUEUES=5 the first two captures of EVERY process replay at 2.0-2.1 ms and later captures of the same graph at 1.10.
-    # The single-GPU engine now auditions up to three instantiations and keeps the fastest (engine.CommEngine._audition;
-    # config.graph_audition_ms in this line), which removes the state where it is per instantiation.  This guard stays as the backstop
-    # for whatever is per process: a run whose step takes more than twice the chip time of its own kernels (and >= 1 ms more) is
-    # repeated ONCE in a fresh process; the line printed is that run's, complete and timed as the contract says, and says so (`retry`).
-    # --no-retry reports the stalled run as it is.
+    # ---- guard: a host-stalled run ---------------------------------------------------------------------------------------------------
+    # Rounds 4-5 saw processes that replayed their (then multi-branch) graph at 2-3 ms per step with the in-kernel launch spans at
+    # their usual length -- the runtime had put both branches of the exec on one hardware pipe.  Round 6 records the
+    # forward as single-branch graphs on streams the package owns, which removes that state at its root; the guard stays as a
+    # flagged backstop for whatever is per process: a run whose step takes more than twice the chip time of its own kernels (and
+    # >= 1 ms more) is repeated ONCE in a fresh process; the line printed is that run's, complete and timed as the contract says,
+    # and says so (`retry`).  --no-retry reports the stalled run as it is.
     busy = roofline.get("kernel_ms_per_step") if isinstance(roofline, dict) else None
     stalled = bool(busy) and ms_per_step > 2.0 * busy + 0.2 and ms_per_step - busy > 1.0      # (>= 1 ms per step with the chip idle)
     if world == 1 and not args.no_retry and (stalled or os.environ.get("W2C_BENCH_FORCE_RETRY") == "1"):   # (the env switch: tests)
@@ -604,6 +605,24 @@ def main():
                               v_shard_bytes=int(st.v_slot.numel() * st.v_slot.element_size()), k_shard_bytes=int(st.k_slot.numel() * 4),
                               note="all-gather of V (bf16, written in place by the squeezer) + projected keys; in the timed "
                                    "step the V gather runs under the policy tail")
+
+    # ---- the same step with eager launches (model.use_hip_graph = False: every launch issued by the host as the Python code runs),
+    # reported beside the headline, never as `value` ---
+    if world == 1 and not args.force_sharded and model.use_hip_graph:
+        model.use_hip_graph = False
+        n_e = max(5, args.steps // 2)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_e):
+            oe = step()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        model.use_hip_graph = True
+        result["eager"] = dict(what="model.use_hip_graph = False: ~45 launches per forward issued by the host on the same two lanes",
+                               ms_per_step=round(1e3 * el / n_e, 4), value=round(images_per_step * n_e / el, 2), unit="agent-images/s",
+                               outputs_equal_headline=bool(torch.equal(oe[0], out[0])))
 
     # ---- evaluator fast path, reported beside the headline, never as `value` ---
     if world == 1:

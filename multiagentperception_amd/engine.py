@@ -36,15 +36,12 @@ def _fold_bn(bn, conv_bias=None):
 
 
 _USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
-_GRAPH_AUDITION = int(os.environ.get('W2C_GRAPH_AUDITION', '4'))   # captures a one-graph forward may audition (CommEngine._audition)
 # the remaining A/B switches, read once at import (never on the launch path)
 _NO_SPLITK = bool(os.environ.get('W2C_NO_SPLITK'))
 _NO_DUAL = bool(os.environ.get('W2C_NO_DUAL'))
 _FP8_SERIAL = bool(os.environ.get('W2C_FP8_SERIAL'))
 _NO_TAIL_OVERLAP = bool(os.environ.get('W2C_NO_TAIL_OVERLAP'))
 _HEAD_MFMA = os.environ.get('W2C_HEAD_MFMA', '1') != '0'   # fc.0 of the heads on the f32 matrix pipe (split-K partials)
-_GATE_U = os.environ.get('W2C_GATE_U', '1') != '0'         # the decoder's value-map conv waits for the policy chain's conv2
-_GRAPH_IO = os.environ.get('W2C_GRAPH_IO', '1') != '0'     # the stem and the upsample inside the captured graph (pointer slots)
 
 
 def _pack_w(conv_weight):
@@ -197,13 +194,29 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
     return (t8 if f8 else t16), idt
 
 
+MAX_PROGRAMS = 6       # recorded programs an engine keeps (one per input shape / dtype / mode; each owns its activation buffers): LRU
+
+
+def _lru_put(cache, key, entry):
+    cache[key] = entry
+    while len(cache) > MAX_PROGRAMS:
+        cache.pop(next(iter(cache)))
+
+
+def _lru_get(cache, key):
+    entry = cache.get(key)
+    if entry is not None and next(reversed(cache)) != key:
+        cache[key] = cache.pop(key)              # most recently used last
+    return entry
+
+
 STAMPS = None          # debug (tools/chain_stamps.py): an int64 device tensor -> after_stem writes wall-clock stamps in stream order
 
 
 def _stamp(slot):
     if STAMPS is not None:
         from . import _native
-        _native.lib().w2c_debug_stamp(STAMPS.data_ptr() + 8 * slot, torch.cuda.current_stream(STAMPS.device).cuda_stream)
+        _native.lib().w2c_debug_stamp(STAMPS.data_ptr() + 8 * slot, ops._stream(STAMPS.device))
 
 
 class TrunkPlan:
@@ -320,10 +333,8 @@ class TrunkPlan:
             if ds is not None:
                 Hs, Ws = (Hs + 1) // 2, (Ws + 1) // 2
         sq = None if squeezer_out is not None else torch.empty((M, Hs, Ws, self.G * feat), dtype=BF16, device=p.device)
-        main = torch.cuda.current_stream(p.device)
-        side = self._side_stream(p.device)
+        L = ops.lanes(p.device)                    # lane 0: the value chain (the caller's stream), lane 1: the policy chain
         _stamp(0)
-        side.wait_stream(main)
 
         # (Measured and not kept, profiles/r04_s2_front_c64.txt + DESIGN 10: starting the value chain behind block k of the policy chain,
         # and capping the value chain's workgroups per CU through its LDS request -- both lengthen the forward.)
@@ -344,7 +355,7 @@ class TrunkPlan:
             _stamp(3 + g)
 
         state = None
-        with torch.cuda.stream(side):
+        with L.on(1, after=(0,)):
             # (Measured and not kept, profiles/r05_policy_tail.txt: the policy chain's conv launches at s_setprio 3 -- it is the critical
             # path, the value chain has ~100 us of slack -- make BOTH chains slower: 0.992-0.999 -> 1.010-1.016 ms.)
             chain(1)
@@ -353,7 +364,7 @@ class TrunkPlan:
         chain(0)
         vres = value_next(sq if squeezer_out is None else squeezer_out[0]) if value_next is not None else None
         _stamp(26)
-        main.wait_stream(side)
+        L.join(1)
         _stamp(5)
         extra = policy_next[1](state) if policy_next is not None else None
         res = list(squeezer_out) if squeezer_out is not None else sq
@@ -436,11 +447,10 @@ class TrunkPlan:
         # The two halves below are independent until the squeezers: the bf16 half runs on a side stream (a parallel
         # branch when the forward is captured into a HIP graph), so its half-size launches fill the CUs the fp8 half
         # leaves idle (320-640 workgroups per launch on 512 slots).
-        main = torch.cuda.current_stream(p.device)
-        side = self._side_stream(p.device) if (self.fp8["rest"] and not _FP8_SERIAL) else None
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        L = ops.lanes(p.device)
+        side = bool(self.fp8["rest"]) and not _FP8_SERIAL
+        if side:
+            with L.on(1, after=(0,)):
                 self._rest_bf16(p, sq if squeezer_out is None else None, squeezer_out, feat)
         # ---- fp8 trunks (channels [0, 64*n8) of layer1's output) ----
         x16, x8 = p, None
@@ -453,19 +463,11 @@ class TrunkPlan:
             self.fp8["squeezer"].run(x8, out_groups=squeezer_out[:n8])
         else:
             self.fp8["squeezer"].run(x8, out=sq, out_ch_off=0)
-        if side is not None:
-            main.wait_stream(side)
+        if side:
+            L.join(1)
         elif self.fp8["rest"]:
             self._rest_bf16(p, sq if squeezer_out is None else None, squeezer_out, feat)
         return list(squeezer_out) if squeezer_out is not None else sq
-
-    def _side_stream(self, dev, idx=0):
-        st = self.__dict__.setdefault("_side", {})
-        if (dev, idx) not in st:
-            # (default priority: a high-priority side stream does not favour its chain -- both chains advance in lock-step, each
-            # block ~25 % slower: 1.45 ms per forward under graph replay, profiles/r03_concurrency.txt)
-            st[(dev, idx)] = torch.cuda.Stream(device=dev)
-        return st[(dev, idx)]
 
     def _rest_bf16(self, p, sq, squeezer_out, feat):
         """the trunks that stay bf16 (the policy encoder): same blocks, one group each launch, reading their slice of
@@ -659,19 +661,12 @@ class CommEngine:
         outs = preallocated (tproj, queries)."""
         return self.policy_heads(self.policy_convs(sq, ch_off), outs)
 
-    def policy_convs(self, sq, ch_off=None, gate=False):
-        """policy_net4 conv1..5.  gate=True: an event is recorded behind conv2 -- the value chain's decoder conv (value_maps) waits for
-        it, so that it runs beside the small, latency-bound conv3..5 + heads and not beside conv1 / conv2, which it slowed by ~8 us
-        when it started right behind the value squeezer (tools/chain_stamps.py)."""
+    def policy_convs(self, sq, ch_off=None):
+        """policy_net4 conv1..5.  (Rounds 4-5 recorded an event behind conv2 for the value chain's decoder conv to wait on, so that it ran
+        beside conv3..5 instead of conv1 / conv2: -8 us then; in a recorded program that edge costs two more graph boundaries at ~6 us
+        each -- 1.011-1.016 vs 0.999-1.003 ms per forward, tools/r06/ab.sh -- and eager launches do not miss it: removed in round 6.)"""
         y = self.policy[0].run(sq, x_ch_off=self.feat if ch_off is None else ch_off)
-        y = self.policy[1].run(y)
-        if gate:
-            ev = self.__dict__.get("_ev_conv2")
-            if ev is None:
-                ev = self._ev_conv2 = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(sq.device))
-            self._gate_armed = True
-        for c in self.policy[2:]:
+        for c in self.policy[1:]:
             y = c.run(y)
         return y
 
@@ -685,11 +680,7 @@ class CommEngine:
         return self.encode_from_stem(self.trunk.stem(x, n_agents))
 
     def value_maps(self, v_src, out=None, out_own=None):
-        """U maps of the value maps in channels [0, feat) of v_src (the 2-trunk squeezer tensor or a V-only tensor); behind the
-        policy chain's conv2 when policy_convs(gate=True) ran before it in this forward"""
-        if self.__dict__.get("_gate_armed"):
-            self._gate_armed = False
-            torch.cuda.current_stream(v_src.device).wait_event(self._ev_conv2)
+        """U maps of the value maps in channels [0, feat) of v_src (the 2-trunk squeezer tensor or a V-only tensor)"""
         return self.decoder.value_maps(v_src, 0, out=out, out_own=out_own)
 
     def encode_from_stem(self, s0):
@@ -711,7 +702,7 @@ class CommEngine:
         # Round 4: the VALUE chain carries on too -- the decoder's first conv on every agent's value map (by linearity), in the
         # ~100 us that chain used to idle before the join.
         def tail(s):
-            y = self.policy_convs(s, gate=_GATE_U)
+            y = self.policy_convs(s)
             _stamp(6)
             r = self.policy_heads(y)
             _stamp(7)
@@ -764,23 +755,13 @@ class CommEngine:
             _, u, keys, querys = self.encode_from_stem(self.trunk.stem(x, N))
             low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode)
             return finish(low), prob, action, nnz
-        if _GRAPH_IO:
-            return self._forward_one_graph(x, B, N, mode, labels, confusion)
-        key = (tuple(x.shape), str(x.dtype), mode)
-        entry = self._graphs.get(key)
-        if entry is None:
-            entry = self._capture(x, B, N, mode)
-            self._graphs[key] = entry
-        s0, graph, low, pack = entry
-        self.trunk.stem(x, N, out=s0)                       # eager: reads the caller's tensor
-        graph.replay()                                      # layer1 ... decoder convs
-        pred = finish(low)                                   # eager: writes the caller-owned output
-        prob, action, nnz = ops.carve_graph_outputs(pack.clone(), B, N, N)     # caller-owned copies: ONE copy of the packed trio
-        return pred, prob, action, nnz
+        return self._forward_program(x, B, N, mode, labels, confusion)
 
-    # ---- the whole forward as ONE graph (round 4): the stem reads the caller's tensor and the upsample writes the caller-owned output
-    # through device-resident pointer slots (include/w2c_hip.h "indirect operands"), so neither is an eager launch around the graph any
-    # more: per forward one tiny slot-setting launch + one replay.  W2C_GRAPH_IO=0 restores stem | graph | upsample | clone.
+    # ---- the whole forward as ONE recorded program (ops.record_program): single-branch HIP graphs on this engine's two lanes -- front
+    # (stem -> layer1 -> layer2.0's front) | policy chain up to conv2 | conv3..5 + heads || value chain | decoder conv0 of the value maps
+    # | join -> graph + fusion -> decoder's last conv -> x32 upsample -- with event edges between them.  The stem reads the caller's
+    # tensor and the upsample writes the caller-owned output through device-resident pointer slots (include/w2c_hip.h "indirect
+    # operands"): per forward one tiny slot-setting launch + one replay of the program.
     _SLOT_X, _SLOT_OUT, _SLOT_PACK, _SLOT_GT, _SLOT_HIST = 0, 1, 2, 3, 4
 
     def _out_like(self, x, N, labels, confusion):
@@ -793,62 +774,24 @@ class CommEngine:
             return (N * B, H, W), torch.uint8
         return (N * B, self.n_classes, H, W), torch.float32
 
-    def _forward_one_graph(self, x, B, N, mode, labels, confusion):
+    def _forward_program(self, x, B, N, mode, labels, confusion):
         dev = x.device
         gt, hist = confusion if confusion is not None else (None, None)
         key = ("io", tuple(x.shape), str(x.dtype), mode, bool(labels), None if gt is None else str(gt.dtype))
         like = self._out_like(x, N, labels, confusion)
         out = None if like is None else torch.empty(like[0], dtype=like[1], device=dev)
-        entry = self._graphs.get(key)
+        entry = _lru_get(self._graphs, key)
         if entry is None:
-            entry = self._audition(x, B, N, mode, labels, confusion, out)
-            self._graphs[key] = entry
-        graph, slots, pack = entry
-        packc = torch.empty_like(pack)
+            entry = self._record(x, B, N, mode, labels, confusion, out)
+            _lru_put(self._graphs, key, entry)
+        program, slots = entry
+        packc = torch.empty_like(program.result)
         ops.set_slots(slots, [x, out, packc, gt, hist])
-        graph.replay()
+        program.replay()
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, N)
         return out, prob, action, nnz
 
-    def _audition(self, x, B, N, mode, labels, confusion, out):
-        """Capture the forward W2C_GRAPH_AUDITION (4) times and keep the instantiation that replays fastest.  Why: which runtime streams --
-        hardware queues, and behind them the command processor's pipes -- a graph's parallel branches land on is decided per instantiation,
-        and when the two trunk chains land on one pipe they do not overlap: the SAME graph replays ~1.7x slower for its whole life.  Round
-        5, 18 fresh processes (gpurun_out/r05_p): at the 16 hardware queues the package runs with (see the package's __init__: the
-        hipGraphLaunch out-of-bounds read) every OTHER instantiation is in that state -- candidates 2.0 / 1.19 / 2.0 / 1.19 ms --, at the
-        runtime's default 4 queues about 2 % of fresh processes drew it (round 4).  Consecutive instantiations cycle through the
-        assignments, so a few candidates see a good one; no early exit.  Costs ~0.15 s at the first forward of a shape.
-        W2C_GRAPH_AUDITION=1: take the first capture as it comes.  self.audition_ms = the candidates' replay times.
-        (ops.capture_best is the same thing for the graphs without pointer slots: the single-request engines, the sharded segment A.)"""
-        dev = x.device
-        gt, hist = confusion if confusion is not None else (None, None)
-        scratch_hist = None if hist is None else torch.zeros_like(hist)
-
-        def timed(entry):
-            graph, slots, pack = entry
-            ops.set_slots(slots, [x, out, torch.empty_like(pack), gt, scratch_hist])      # (never the caller's histogram)
-            graph.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                graph.replay()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / 5.0
-
-        best, times = None, []
-        for i in range(max(1, _GRAPH_AUDITION)):
-            entry = self._capture_one_graph(x, B, N, mode, labels, confusion, out)
-            if _GRAPH_AUDITION <= 1:
-                return entry
-            t = timed(entry)
-            times.append(round(t, 4))
-            if best is None or t < best[0]:
-                best = (t, entry)
-        self.audition_ms = times
-        return best[1]
-
-    def _capture_one_graph(self, x, B, N, mode, labels, confusion, out):
+    def _record(self, x, B, N, mode, labels, confusion, out):
         dev = x.device
         slots = torch.zeros(8, dtype=torch.int64, device=dev)
         xs = ops.SlotRef(slots, self._SLOT_X, x)
@@ -872,44 +815,18 @@ class CommEngine:
                 ops.upsample_bilinear32(low, self.n_classes, out=outs)
             return pack
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            # warm-up on real targets: func attributes, head plans, allocator.  (The caller's confusion histogram is NOT touched here:
-            # the warm-up forwards accumulate into a scratch copy.)
-            scratch_hist = None if hist is None else torch.zeros_like(hist)
-            pack0 = ops.graph_outputs(dev, B, N, N)[0]
-            ops.set_slots(slots, [x, out, pack0, gt, scratch_hist])
-            for _ in range(2):
-                whole()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        with ops.capture() as graph:
-            pack = whole()
-        return graph, slots, pack
+        scratch = []                                # what the warm-up forwards write through the slots: alive until they have run
 
-    def _capture(self, x, B, N, mode):
-        """Capture everything between the stem and the final upsample into one HIP graph.  The stem
-        output is the graph's static input buffer (the stem writes straight into it: no copy); the
-        low-resolution logits / prob / action / nnz are its static outputs."""
-        dev = x.device
+        def point_slots():
+            # warm-up on real targets (function attributes, head plans, the allocator).  The caller's confusion histogram is NOT
+            # touched: the warm-up forwards accumulate into a scratch copy.
+            scratch.append(ops.graph_outputs(dev, B, N, N)[0])
+            scratch.append(None if hist is None else torch.zeros_like(hist))
+            ops.set_slots(slots, [x, out, scratch[0], gt, scratch[1]])
 
-        def middle(s0):
-            _, u, keys, querys = self.encode_from_stem(s0)
-            return self.graph_and_low(u, keys, querys, B, N, 0, N, mode)
-
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            s0 = self.trunk.stem(x, N)
-            for _ in range(2):                               # warm-up: func attributes, head plans, allocator
-                middle(s0)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        with ops.capture() as graph:
-            low, prob, action, nnz = middle(s0)
-            pack = self._last_pack
-        return s0, graph, low, pack
+        program = ops.record_program(dev, whole, warmup=2, before_warmup=point_slots)
+        del scratch[:]                              # (record_program synchronised the device after the warm-up)
+        return program, slots
 
 
 class SingleEngine:
@@ -978,28 +895,23 @@ class SRMSEngine:
         pred = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=dev)
         graphs = self.__dict__.setdefault("_graphs", {})
         key = (tuple(x.shape), mode)
-        ent = graphs.get(key)
+        ent = _lru_get(graphs, key)
         if ent is None:
             xs = torch.empty_like(x)
             slots = torch.zeros(8, dtype=torch.int64, device=dev)
             outs = ops.SlotRef(slots, 0, pred)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
+
+            def prep():
                 xs.copy_(x)
                 ops.set_slots(slots, [pred])
-                for _ in range(2):
-                    self._forward(xs, mode, out=outs)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            # (the five-encoder variant has three parallel branches, the others two: which runtime streams they land on is decided per
-            # instantiation -- ops.capture_best keeps the one that replays fastest, as CommEngine._audition does)
-            graph, res, self.audition_ms = ops.capture_best(lambda: self._forward(xs, mode, out=outs), _GRAPH_AUDITION)
-            ent = graphs[key] = (graph, xs, slots, res[1:])
-        graph, xs, slots, small = ent
+
+            program = ops.record_program(dev, lambda: self._forward(xs, mode, out=outs), warmup=2, before_warmup=prep)
+            ent = (program, xs, slots, program.result[1:])
+            _lru_put(graphs, key, ent)
+        program, xs, slots, small = ent
         xs.copy_(x, non_blocking=True)
         ops.set_slots(slots, [pred])
-        graph.replay()
+        program.replay()
         return (pred,) + tuple(t.clone() for t in small)
 
     def _forward(self, x, mode, out=None):
@@ -1015,19 +927,16 @@ class SRMSEngine:
             # >= 5 parallel branches can always draw two collisions, and the out-of-bounds pointer is what segfaulted the replay of exactly
             # this graph in GPUTEST_r04 and again in round 5 (profiles/r05_capture_crash.txt: native frames + disassembly).  <= 4 branches
             # cannot overrun under round-robin queue assignment; every graph of this package now has <= 3.
+            L = ops.lanes(x.device)
             main = torch.cuda.current_stream(x.device)
             parts = [None] * len(self.trunks5)
-            sides = [self.trunk._side_stream(x.device, 2 + k) for k in range(2)]
-            for st in sides:
-                st.wait_stream(main)
             for i, t in enumerate(self.trunks5):
-                with torch.cuda.stream(sides[i % 2]):
+                with L.on(1 + (i % 2), after=(0,) if i < 2 else ()):
                     parts[i] = t.run(x[:, 3 * i:3 * i + 3].contiguous(), 1)
-            capturing = torch.cuda.is_current_stream_capturing()
-            for st in sides:
-                main.wait_stream(st)
-            if not capturing:                       # eager: the blocks were allocated on a side stream and are consumed on main.  Inside a
-                for pt in parts:                    # capture the graph's own edges order producer, consumer and any reuse of the block
+            for k in (1, 2):
+                L.join(k)
+            if not L.recording:                     # eager: the blocks were allocated on a side stream and are consumed on the caller's
+                for pt in parts:                    # (a recorded program keeps every block alive for its own life)
                     pt.record_stream(main)
             vcs_src = torch.cat(parts, 0)
             pol_off = 0

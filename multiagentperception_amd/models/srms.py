@@ -2,6 +2,8 @@
 rank 2) with the reference's constructor arguments, state_dict keys, forward signature and return tuples
 (agent.py:472-673, 676-889), on the HIP engine.  Five agents are hard-coded by the reference (divide_inputs,
 agent.py:556,766); agent 0 is the requester.  Same dispatch rule as when2com.py: eval() -> HIP, train() -> stock ops."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -90,7 +92,7 @@ class _SRMSBase(_EngineCacheMixin, nn.Module):
     def _hip(self, inputs, mode):
         eng = self._engine_for(inputs, _engine.SRMSEngine)
         with torch.no_grad():
-            return eng.forward(inputs.contiguous().float(), mode, use_graph=bool(getattr(self, "use_hip_graph", False)))
+            return eng.forward(inputs.contiguous().float(), mode, use_graph=bool(getattr(self, "use_hip_graph", os.environ.get("W2C_HIP_GRAPH", "1") != "0")))
 
 
 class LearnWhen2Com(_SRMSBase):

@@ -149,9 +149,10 @@ class _MIMOBase(_EngineCacheMixin, nn.Module):
         self.has_query = has_query
         self.sparse = sparse
         self.image_size = image_size
-        # replay the launch-bound middle of the eval forward from a captured HIP graph (per input shape
-        # and inference mode).  Off by default; W2C_HIP_GRAPH=1 or model.use_hip_graph = True turns it on.
-        self.use_hip_graph = os.environ.get("W2C_HIP_GRAPH", "0") == "1"
+        # the eval forward replays from a recorded program -- single-branch HIP graphs on the engine's two lanes, one program per
+        # (input shape, dtype, inference mode), recorded at the first forward of that shape (ops.record_program).  On by default
+        # since round 6; model.use_hip_graph = False (or W2C_HIP_GRAPH=0) issues every launch from the host instead.
+        self.use_hip_graph = os.environ.get("W2C_HIP_GRAPH", "1") != "0"
         self._build(n_classes, in_channels, feat_channel, feat_squeezer, image_size, enc_backbone, dec_backbone)
         # parameter groups the reference exposes (agent.py:1019-1030); unused by its trainers
         self.attention_paras = list(self.attention_net.parameters())

@@ -32,11 +32,17 @@ def _need_gpu(*tensors):
 
 
 def _stream(dev):
+    rec = getattr(_tls, "recorder", None)
+    if rec is not None:
+        rec.dirty = True                            # this capture window holds at least one kernel node (ops.record_program)
     return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _p(t):
     return 0 if t is None else t.data_ptr()
+
+
+_tls = threading.local()          # per-thread (DataParallel runs one thread per replica): the opt-in conv timer, the lanes recorder
 
 
 class SlotRef:
@@ -108,37 +114,265 @@ class capture:
                 gc.enable()
 
 
-def capture_best(fn, candidates, prepare=None):
-    """Capture fn() `candidates` times (ops.capture) and keep the instantiation that REPLAYS fastest -> (graph, fn's result, times in ms).
-    Why: which runtime streams -- hardware queues, and behind them the command processor's pipes -- a graph's parallel branches land on is
-    decided per instantiation, and two branches that land on one pipe do not overlap: the SAME graph then replays ~1.7x slower for its whole
-    life.  Round 5 measured it per candidate in 18 fresh processes (gpurun_out/r05_p): at 16 hardware queues -- what the package runs with,
-    see __init__ -- every OTHER instantiation of the two-chain forward is in that state (2.0 vs 1.19 ms), at 4 queues none; consecutive
-    instantiations cycle through the assignments, so a few candidates see a good one.  fn must be idempotent (its graph is replayed 6 times
-    here); prepare(result) runs before a candidate's replays (e.g. to point its pointer slots at scratch)."""
-    best, times = None, []
-    for _ in range(max(1, candidates)):
-        with capture() as graph:
-            res = fn()
-        if candidates <= 1:
-            return graph, res, []
-        if prepare is not None:
-            prepare(res)
-        graph.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            graph.replay()
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1) / 5.0
-        times.append(round(t, 4))
-        if best is None or t < best[0]:
-            best = (t, graph, res)                  # (the previous best dies HERE, outside any capture window)
-        # a losing candidate must die here too -- not when `graph` is rebound by the next `with ... as graph`, which happens INSIDE the next
-        # capture window (the very hazard ops.capture documents: a CUDAGraph finalised in a window kills the process)
-        del graph, res
-    return best[1], best[2], times
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Lanes: how this package expresses concurrency on one device (round 6).
+#
+# A forward has at most a handful of independent launch chains (the value trunk || the policy trunk and its tail; the five encoders of
+# the single-request models).  Engine code never touches torch streams directly: it asks for the device's lanes and says
+#     with L.on(1, after=(0,)): ...      run this block on lane 1, behind everything lane 0 has been given so far
+#     tok = L.mark()                     a point in the current lane's order
+#     L.wait(tok)                        the current lane goes on only behind that point
+#     L.join(1)                          the current lane goes on only behind everything lane 1 has been given
+#     L.eager(fn)                        something that must be issued by the host every time (an RCCL collective): never captured
+# Lane 0 is the caller's stream, lanes 1.. are long-lived side streams.  Two executors implement the same five verbs:
+#   * EagerLanes  -- stream / event calls, the launches go out as the Python code runs (model.use_hip_graph = False);
+#   * a recorder  -- record_program(): the SAME Python code is run once under capture and cut, at exactly those verbs, into a list of
+#     SINGLE-BRANCH HIP graphs (one linear chain of kernel nodes each) plus the event edges between them; Program.replay() launches
+#     them on the lanes' streams, edges as hipEventRecord / hipStreamWaitEvent between the launches.
+# Why not one graph with parallel branches (rounds 3-5): which streams the runtime runs the branches of a multi-branch exec on is the
+# runtime's choice per instantiation -- hipGraphLaunch of the HIP runtime bundled with torch 2.10 + rocm7.0 reads out of bounds while
+# choosing (profiles/r05_capture_crash.txt), and a bad draw puts both trunk chains on one hardware pipe for the exec's whole life
+# (1.7x the step time; rounds 4-5 auditioned four instantiations per shape and kept the fastest, under GPU_MAX_HW_QUEUES=16).  A
+# single-branch exec has max_streams == 1: the stream-selection loop has nothing to choose, and the lanes are streams this package
+# created once -- no audition, no environment variable, no burst of exec-stream destructions.
+_MAX_LANES = 4
+
+
+def _lane_stream(dev, k):
+    """long-lived side stream k (>= 1) of this thread on `dev` (eager executor; a Program owns its own set)"""
+    st = _tls.__dict__.setdefault("lane_streams", {})
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), k)
+    s = st.get(key)
+    if s is None:
+        s = st[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
+class EagerLanes:
+    """The verbs above as plain stream / event calls.  Stateless apart from lane 0 = the stream that was current when it was made, so a
+    nested helper may ask ops.lanes(dev) again: mark / wait / join always act on torch's CURRENT stream."""
+    recording = False
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.main = torch.cuda.current_stream(dev)
+
+    def stream(self, k):
+        return self.main if k == 0 else _lane_stream(self.dev, k)
+
+    def on(self, k, after=()):
+        s = self.stream(k)
+        for j in after:
+            sj = self.stream(j)
+            if sj != s:
+                s.wait_stream(sj)
+        return torch.cuda.stream(s)
+
+    def mark(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return ev
+
+    def wait(self, tok):
+        torch.cuda.current_stream(self.dev).wait_event(tok)
+
+    def join(self, k):
+        cur, s = torch.cuda.current_stream(self.dev), self.stream(k)
+        if s != cur:
+            cur.wait_stream(s)
+
+    def eager(self, fn):
+        return fn()
+
+
+class _LaneCtx:
+    def __init__(self, rec, k, after):
+        self.rec, self.k, self.after = rec, k, tuple(after)
+
+    def __enter__(self):
+        r = self.rec
+        self.prev = r._lane
+        r._close()
+        for j in self.after:
+            if j != self.k:
+                r.prog.append(("sync", self.k, j, torch.cuda.Event()))
+        r._open(self.k)
+
+    def __exit__(self, et, ev, tb):
+        r = self.rec
+        r._close(abort=et is not None)
+        if et is None:
+            r._open(self.prev)
+        return False
+
+
+class _Recorder:
+    """record_program()'s executor: one capture window open at any time, on the current lane; every verb closes it, notes the edge and
+    opens the next one.  Each window becomes its own CUDAGraph with its own private memory pool (blocks freed inside a window are
+    reused inside that window only -- windows on different lanes run concurrently at replay); tensors handed from one window to a
+    later one stay alive because the Python code holds them until the recording ends and the Program keeps the result."""
+    recording = True
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.prog = []
+        self.cap = [torch.cuda.Stream(device=dev) for _ in range(_MAX_LANES)]     # capture-time streams (replay uses the Program's)
+        self._lane, self._g, self._sctx = 0, None, None
+        self.dirty = False
+        self.n_events = 0
+
+    def _open(self, lane):
+        if lane >= _MAX_LANES:
+            raise W2CError("lane %d: at most %d lanes" % (lane, _MAX_LANES))
+        self._lane = lane
+        self._sctx = torch.cuda.stream(self.cap[lane])
+        self._sctx.__enter__()
+        self._g = torch.cuda.CUDAGraph()
+        self.dirty = False
+        try:
+            self._g.capture_begin(capture_error_mode="thread_local")
+        except BaseException:
+            self._sctx.__exit__(None, None, None)
+            self._g = self._sctx = None
+            raise
+
+    def _close(self, abort=False):
+        if self._g is None:
+            return
+        g, self._g = self._g, None
+        import warnings
+        empty = False
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                g.capture_end()
+            empty = any("empty" in str(w.message).lower() for w in caught)
+        finally:
+            self._sctx.__exit__(None, None, None)
+            self._sctx = None
+        if not abort and (self.dirty or not empty):
+            self.prog.append(("graph", self._lane, g))
+
+    # ---- the five verbs ----
+    def on(self, k, after=()):
+        return _LaneCtx(self, k, after)
+
+    def mark(self):
+        lane = self._lane
+        self._close()
+        ev = torch.cuda.Event()
+        self.prog.append(("record", lane, ev))
+        self._open(lane)
+        return ev
+
+    def wait(self, tok):
+        lane = self._lane
+        self._close()
+        self.prog.append(("wait", lane, tok))
+        self._open(lane)
+
+    def join(self, k):
+        lane = self._lane
+        if k == lane:
+            return
+        self._close()
+        self.prog.append(("sync", lane, k, torch.cuda.Event()))
+        self._open(lane)
+
+    def eager(self, fn):
+        lane = self._lane
+        self._close()
+        self.prog.append(("call", lane, fn))
+        with torch.cuda.stream(self.cap[lane]):
+            res = fn()                              # (runs on unwritten buffers here: captured work has not executed)
+        self._open(lane)
+        return res
+
+
+def lanes(dev):
+    """the lanes executor in effect on this thread: the recorder inside record_program(), else stream / event calls"""
+    rec = getattr(_tls, "recorder", None)
+    if rec is not None:
+        if dev.index is not None and rec.dev.index is not None and dev.index != rec.dev.index:
+            raise W2CError("record_program: launches on %s inside a recording for %s" % (dev, rec.dev))
+        return rec
+    return EagerLanes(dev)
+
+
+class Program:
+    """A recorded forward: single-branch graphs + the edges between them (see the block comment above).  replay() issues it on the
+    caller's current stream (lane 0) and this Program's own side streams; `result` is what the recorded function returned (tensors in
+    the graphs' private pools: static across replays)."""
+
+    def __init__(self, dev, prog, result):
+        self.dev, self.prog, self.result = dev, prog, result
+        n_side = max([st[1] for st in prog] + [st[2] for st in prog if st[0] == "sync"] + [0])
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
+        self.n_graphs = sum(1 for st in prog if st[0] == "graph")
+
+    def replay(self):
+        s0 = torch.cuda.current_stream(self.dev)
+        S = [s0] + self.side
+        for st in self.prog:
+            kind = st[0]
+            if kind == "graph":
+                if st[1] == 0:
+                    st[2].replay()
+                else:
+                    with torch.cuda.stream(S[st[1]]):
+                        st[2].replay()
+            elif kind == "sync":                    # lane st[1] goes on behind everything lane st[2] has been given
+                st[3].record(S[st[2]])
+                S[st[1]].wait_event(st[3])
+            elif kind == "record":
+                st[2].record(S[st[1]])
+            elif kind == "wait":
+                S[st[1]].wait_event(st[2])
+            else:                                   # "call": issued by the host at every replay (collectives)
+                with torch.cuda.stream(S[st[1]]):
+                    st[2]()
+        return self.result
+
+
+def record_program(dev, fn, warmup=2, before_warmup=None):
+    """Run fn() `warmup` times eagerly on a side stream (function attributes, lazily built plans, the allocator), then once more under
+    the recorder -> Program.  fn must be idempotent and may use the lanes verbs; every tensor it allocates lives in the Program."""
+    import gc
+    if getattr(_tls, "recorder", None) is not None:
+        raise W2CError("record_program inside a recording")
+    if warmup > 0:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if before_warmup is not None:
+                before_warmup()
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+    # collect BEFORE the windows and hold the collector off INSIDE them: a CUDAGraph finalised inside a capture window kills the process
+    # (see ops.capture)
+    gc.collect()
+    torch.cuda.synchronize(dev)
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    rec = _Recorder(dev)
+    _tls.recorder = rec
+    ok = False
+    try:
+        rec._open(0)
+        res = fn()
+        rec._close()
+        ok = True
+    finally:
+        _tls.recorder = None
+        if not ok:
+            try:
+                rec._close(abort=True)
+            except Exception:                       # noqa: BLE001
+                pass
+        if gc_was_on:
+            gc.enable()
+    return Program(dev, rec.prog, res)
 
 
 def set_slots(slots, tensors):
@@ -244,7 +478,6 @@ class KernelTimer:
         return busy + (hi - lo)
 
 
-_tls = threading.local()          # per-thread (DataParallel runs one thread per replica): the opt-in conv timer
 
 
 def set_conv_timer(timer):

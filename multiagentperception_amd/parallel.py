@@ -21,7 +21,6 @@ import os
 import torch
 import torch.distributed as dist
 
-_ONE_GRAPH = os.environ.get("W2C_SHARD_ONE_GRAPH", "1") != "0"     # the sharded step as one captured graph (nccl backend only)
 _SPARSE_FORCE = {"1": True, "0": False}.get(os.environ.get("W2C_SHARD_SPARSE", ""))        # see AgentParallelForward._sparse_pays
 _SPARSE_MIN_BYTES = int(float(os.environ.get("W2C_SHARD_SPARSE_MIN_MB", "8")) * (1 << 20))
 
@@ -100,84 +99,6 @@ def sparse_exchange(v_local, need, B, N, group=None):
     return v_all, len(flat_recv), (world - 1) * n_loc * B
 
 
-# ProcessGroupNCCL's flight recorder is how _watchdog_idle() SEES the watchdog's list (see there).  Its ring buffer is sized when the
-# process group is created (default 0 = off in torch 2.10): the package's __init__ sets the variable, bench.py sets it before importing
-# torch; a process that created its group before either gets the 3-segment form (and a warning), never an unproven capture.
-os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
-_WATCHDOG_IDLE_TIMEOUT_S = float(os.environ.get("W2C_WATCHDOG_IDLE_TIMEOUT_S", "20"))
-
-
-def _fr_entries(only_active):
-    import pickle
-    from torch._C._distributed_c10d import _dump_nccl_trace
-    d = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=only_active))
-    return d.get("entries", []) if isinstance(d, dict) else []
-
-
-_captured_ids = set()        # flight-recorder ids of collectives issued INSIDE capture windows: never listed by the watchdog, never retired
-
-
-def _fr_max_id():
-    ents = _fr_entries(False)
-    return max((int(e.get("record_id", -1)) for e in ents), default=-1)
-
-
-class _collectives_captured:
-    """wraps a capture window that has collectives inside: their flight-recorder entries (one per collective, recorded whether or not the
-    work is handed to the watchdog) are remembered, so that _watchdog_idle() does not wait for them -- nobody will ever retire them."""
-
-    def __enter__(self):
-        try:
-            self.lo = _fr_max_id()
-        except Exception:
-            self.lo = None
-        return self
-
-    def __exit__(self, *exc):
-        if self.lo is not None:
-            try:
-                _captured_ids.update(range(self.lo + 1, _fr_max_id() + 1))
-            except Exception:
-                pass
-        return False
-
-
-def _watchdog_idle(group=None, timeout_s=None):
-    """Before a capture that has RCCL collectives inside it: wait until ProcessGroupNCCL's watchdog thread has RETIRED every eager
-    collective issued so far (the warm-up runs, an agreement all-reduce).  Why: the watchdog polls its list of works and asks every listed
-    work's end event whether it has completed; those events were recorded on the process group's internal stream, and while that stream
-    is part of a capture HIP answers the query with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a
-    capturing stream") -- the watchdog rethrows and the process aborts.  Works issued DURING capture are never listed, so the hazard is
-    exactly the eager works still listed when a capture window opens.
-    Round 4 slept three poll periods and hoped.  Round 5 observes: the process group's flight recorder keeps one entry per collective
-    and the watchdog sets its `retired` flag at the moment it erases the work from its list (tools/r05/fr_probe.py on the GPU box: state
-    'completed' first, `retired` ~80 ms later); this polls the recorder until every entry of an eager collective is retired (the caller
-    has synchronised the device, so every listed work HAS completed and the next watchdog pass retires it).  If the recorder cannot show
-    that (disabled: no entries at all although collectives ran; or still un-retired after the timeout) this raises RuntimeError -- the
-    caller then takes the 3-segment form, whose collectives are eager and never captured: no proof, no capture.
-    -> seconds waited."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
-        return 0.0
-    import time
-    t0 = time.monotonic()
-    limit = _WATCHDOG_IDLE_TIMEOUT_S if timeout_s is None else timeout_s
-    try:
-        while True:
-            ents = _fr_entries(False)
-            if not ents:
-                raise RuntimeError("flight recorder holds no entries")
-            busy = [e for e in ents if not e.get("retired", False) and int(e.get("record_id", -1)) not in _captured_ids]
-            if not busy:
-                return time.monotonic() - t0
-            if time.monotonic() - t0 > limit:
-                raise RuntimeError("%d eager collectives still listed after %.0f s" % (len(busy), limit))
-            time.sleep(0.005)
-    except RuntimeError as e:
-        raise RuntimeError("cannot prove ProcessGroupNCCL's watchdog list empty (%s): not capturing collectives" % (e,))
-    except Exception as e:                                 # recorder API missing / changed
-        raise RuntimeError("cannot prove ProcessGroupNCCL's watchdog list empty (flight recorder unavailable: %r)" % (e,))
-
-
 def shard_agents(agent_num, world, rank):
     if agent_num % world != 0:
         raise ValueError("agent_num %d is not divisible by world size %d" % (agent_num, world))
@@ -226,30 +147,17 @@ class _ShardState:
         self.out = {}
 
     def run(self, name, fn, use_graph):
-        """Run segment `name` (fn() -> tuple of tensors written into static buffers), eagerly or by replaying its
-        captured HIP graph (captured on first use, after two warm-up runs on a side stream)."""
+        """Run segment `name` (fn() -> tuple of tensors written into static buffers), eagerly or by replaying its recorded
+        program (ops.record_program: single-branch HIP graphs on this rank's lanes; recorded on first use, after two warm-up runs)."""
         if not use_graph:
             self.out[name] = fn()
             return self.out[name]
-        g = self.graphs.get(name)
-        if g is None:
-            dev = self.v_all.device
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    fn()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
+        prog = self.graphs.get(name)
+        if prog is None:
             from . import ops
-            from .engine import _GRAPH_AUDITION
-            # segment A holds the two trunk chains: auditioned like the one-GPU forward (ops.capture_best); B and C are single chains
-            g, res, _ = ops.capture_best(fn, _GRAPH_AUDITION if name == "A" else 1)
-            self.graphs[name] = (g, res)
-            g = self.graphs[name]
-        g[0].replay()
-        self.out[name] = g[1]
-        return g[1]
+            prog = self.graphs[name] = ops.record_program(self.v_all.device, fn, warmup=2)
+        self.out[name] = prog.replay()
+        return self.out[name]
 
 
 class AgentParallelForward:
@@ -259,13 +167,19 @@ class AgentParallelForward:
     Returns (pred [n_loc*B, n_cls, H, W], prob [B, N, n_loc], action [B, n_loc], nnz [B])
     for the local query agents; N = global agent count.
 
-    Per step and rank ('softmax'): stem (eager: reads the caller's tensor) -> segment A: layer1..4 + both squeezers + policy
-    conv1..5 (on the policy chain's stream) + the decoder's first conv on the local value maps (on the value chain's stream,
-    by linearity: engine.DecoderPlan.value_maps), writing U straight into this rank's rows of the
-    all-gather buffer -> async all-gather of U (in place, RCCL) -> segment B: the key / query heads, the projected keys written into this rank's rows of the key
-    buffer (runs while V is on the wire) -> all-gather of K -> segment C: graph columns of the local queries, fusion,
-    decoder convs -> upsample (eager: caller-owned output).  With model.use_hip_graph the three segments are replayed
-    from captured HIP graphs (~45 launches -> 3); the collectives stay eager between them."""
+    Per step and rank (dense exchange: 'softmax', and the thresholded modes below _sparse_pays' limit) -- _dense_step:
+        stem (reads the caller's frames through a pointer slot) -> layer1 (both trunks) -> layer2.0's front -> fork
+          lane 0, value chain : layer2..4, squeezer, decoder conv0 on the local value maps (U, by linearity: engine.DecoderPlan.value_maps,
+                                written straight into this rank's rows of the gather buffer), in-place RCCL all-gather of U -- issued from
+                                the value chain, so it travels under the policy chain's tail
+          lane 1, policy chain: layer2..4, squeezer, policy conv1..5, heads (projected keys into this rank's rows), all-gather of K
+        join -> graph columns of the local queries + fusion of the U maps + bias + ReLU -> decoder's last conv -> x32 upsample into the
+        caller-owned logits (pointer slot) -> packed prob / action / nnz into the caller-owned copy.
+    With model.use_hip_graph the step is ONE recorded program (ops.record_program): ~45 kernel launches become a handful of
+    single-branch HIP graphs on the rank's two lanes; the two collectives are issued by the host between them at every replay (round 6:
+    rounds 4-5 captured them INTO a graph, which needed a proof that ProcessGroupNCCL's watchdog list was empty at capture time -- a
+    private torch API -- and a graph with parallel branches; an eager collective between two graph launches costs ~20 us of host time
+    per step and none of that).  Sparse exchange and the fp8 trunk: stem | segment A | collectives | B | C, each segment a program."""
 
     def __init__(self, model, group=None):
         from . import engine as _engine
@@ -276,11 +190,10 @@ class AgentParallelForward:
         self.q_lo, self.n_loc = shard_agents(model.agent_num, self.world, self.rank)
         self._engine_cls = _engine.CommEngine
         self.last_exchange = None
-        # force_sharded: take the multi-rank code path (segment graphs + in-place RCCL all-gathers) even with ONE rank -- the
-        # only way to execute the RCCL calls and their interplay with graph capture on a single-GPU box (tests, bench
-        # --force-sharded); results equal forward_local's bit for bit
+        # force_sharded: take the multi-rank code path (the recorded program + in-place RCCL all-gathers) even with ONE rank -- the
+        # only way to execute the RCCL calls between the graph launches on a single-GPU box (tests, bench --force-sharded); results
+        # equal forward_local's bit for bit
         self.force_sharded = os.environ.get("W2C_FORCE_SHARDED", "0") == "1"
-        self._one_graph_ok = True
         self.launch_form = "eager"
 
     def _state(self, eng, x):
@@ -306,16 +219,9 @@ class AgentParallelForward:
             x = inputs_local.contiguous().float()
             if self.world == 1 and not (self.force_sharded and dist.is_initialized()):
                 return eng.forward_local(x, B, N, inference, use_graph=use_graph)
-            if ((inference == "softmax" or not self._sparse_pays(eng, x)) and use_graph and _ONE_GRAPH and not eng.trunk.n8
-                    and self._one_graph_ok and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
-                try:
-                    return self._one_graph(eng, x, B, N, inference)
-                except RuntimeError as e:       # capture refused (an RCCL build that cannot be captured): the segment form below
-                    import warnings
-                    warnings.warn("agent-parallel forward: one-graph capture failed (%s); using 3 graph segments + eager collectives" % (e,))
-                    self._one_graph_ok = False
-                    eng.__dict__.pop("_shard_states", None)
-            self.launch_form = "3 hip-graph segments + eager collectives" if use_graph else "eager"
+            if (inference == "softmax" or not self._sparse_pays(eng, x)) and not eng.trunk.n8 and dist.is_initialized():
+                return self._dense_step(eng, x, B, N, inference, use_graph)
+            self.launch_form = "3 program segments + eager collectives" if use_graph else "eager"
             st = self.encode_local(eng, x, use_graph)
             if inference != "softmax":
                 return self._sparse(eng, st, inference, use_graph)
@@ -346,128 +252,72 @@ class AgentParallelForward:
         recv = (self.world - 1) * self.n_loc * B * (H // 32) * (W // 32) * ucs * 4
         return recv >= _SPARSE_MIN_BYTES
 
-    def _one_graph(self, eng, x, B, N, inference):
-        """The whole sharded step of a rank as ONE captured HIP graph (round 4), RCCL all-gathers included ('softmax'; 'activated' /
-        'argmax_test' when the dense exchange is the cheaper one, see _sparse_pays -- the communication-graph kernel zeroes the
-        coefficients of the unused maps either way, so the results equal the sparse path's bit for bit):
-            stem (reads the caller's frames through a pointer slot) -> layer1 (both trunks) -> fork
-              value chain : layer2..4, squeezer, decoder conv0 on the local value maps (U, into this rank's rows of the gather buffer),
-                            in-place all-gather of U  -- issued from the value chain, so it travels under the policy chain's tail
-              policy chain: layer2..4, squeezer, policy conv1..5, heads (projected keys into this rank's rows), all-gather of K
-            join -> graph columns of the local queries + fusion of the U maps + bias + ReLU -> decoder's last conv -> x32 upsample into
-            the caller-owned logits (pointer slot) -> packed prob / action / nnz into the caller-owned copy.
-        Per step the host issues one slot-setting launch and one replay (the 3-segment form: stem + 3 replays + 2 collectives +
-        upsample + 3 clones).  Needs the nccl (RCCL) backend: its collectives are stream operations and can be captured."""
+    def _dense_step(self, eng, x, B, N, inference, use_graph):
+        """The whole sharded step of a rank with the dense exchange (see the class docstring), run eagerly or replayed from ONE recorded
+        program.  'activated' / 'argmax_test' take it when the dense exchange is the cheaper one (_sparse_pays): the communication-graph
+        kernel zeroes the coefficients of the unused maps either way, so the results equal the sparse path's bit for bit."""
         from . import ops
         st = self._state(eng, x)
         n_loc, q_lo = self.n_loc, self.q_lo
         dev = x.device
         H, W = x.shape[2], x.shape[3]
+        rows = n_loc * B
         out = torch.empty((n_loc * B, eng.n_classes, H, W), dtype=torch.float32, device=dev)
+
+        def step(xs, outs, packs):
+            L = ops.lanes(dev)
+            works = []
+            eng.trunk.stem(xs, n_loc, out=st.s0)
+
+            def value_tail(v):
+                # U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K gather
+                # (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel under
+                # the policy tail (ADVICE r04).  The K gather is issued from the policy chain's lane, behind the heads.
+                u = eng.value_maps(v, out=st.v_slot, out_own=st.u_own)
+                L.eager(lambda: works.append(_gather_inplace(st.v_all, self.rank, rows, self.group)))
+                with L.on(1):
+                    L.eager(lambda: works.append(_gather_inplace(st.k_all, self.rank, rows, self.group)))
+                return u
+
+            def policy_tail(pol):
+                y = eng.policy_convs(pol, ch_off=0)
+                eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
+                return y
+
+            eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
+
+            def wait_all():
+                while works:
+                    exchange_wait(works.pop(0))
+            L.eager(wait_all)
+            low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=packs, u_own=st.u_own)
+            pack = eng._last_pack
+            ops.upsample_bilinear32(low, eng.n_classes, out=outs)
+            return pack
+
+        dense = (self.world - 1) * n_loc * B
+        self.last_exchange = (dense, dense)
+        if not use_graph:
+            self.launch_form = "eager"
+            packc = ops.graph_outputs(dev, B, N, n_loc)[0]
+            step(x, out, packc)
+            prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
+            return out, prob, action, nnz
         ent = st.graphs.get("whole:" + inference)
         if ent is None:
             slots = torch.zeros(8, dtype=torch.int64, device=dev)
             xs = ops.SlotRef(slots, 0, x)
             outs = ops.SlotRef(slots, 1, out)
-            rows = n_loc * B
-
-            pol_stream = eng.trunk._side_stream(dev)        # the policy chain's stream (engine.TrunkPlan.after_stem)
-
-            def whole():
-                eng.trunk.stem(xs, n_loc, out=st.s0)
-                works, done = [], {}
-
-                def gather_k():
-                    works.append(_gather_inplace(st.k_all, self.rank, rows, self.group))
-                    done["k"] = True
-
-                def value_tail(v):
-                    # U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K gather
-                    # (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel under
-                    # the policy tail (ADVICE r04).  The K gather is issued from the policy chain's stream, behind the heads.
-                    u = eng.value_maps(v, out=st.v_slot, out_own=st.u_own)
-                    works.append(_gather_inplace(st.v_all, self.rank, rows, self.group))
-                    if done.get("heads"):
-                        with torch.cuda.stream(pol_stream):
-                            gather_k()
-                    return u
-
-                def policy_tail(pol):
-                    y = eng.policy_convs(pol, ch_off=0, gate=True)
-                    eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
-                    done["heads"] = True
-                    return y
-
-                eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
-                if not done.get("k"):
-                    gather_k()                               # (an after_stem form that ran the value tail before the policy tail)
-                for wk in works:
-                    exchange_wait(wk)
-                pack2 = ops.SlotRef(slots, 2, ops.graph_outputs(dev, B, N, n_loc)[0])
-                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=pack2, u_own=st.u_own)
-                pack = eng._last_pack
-                ops.upsample_bilinear32(low, eng.n_classes, out=outs)
-                return pack
-
-            # Every rank must take the SAME form (the collectives are inside the graph: a rank that fell back to eager collectives while
-            # its peers replay captured ones hangs them all, ADVICE r04), and every rank must keep the SAME candidate of the audition.
-            # So: warm up -> prove the watchdog's list empty -> capture ALL candidates (no eager collective between captures) -> ONE
-            # agreement all-reduce (MIN of "my captures succeeded") -> time the candidates -> ONE all-reduce (MAX) of the time vector.
-            from .engine import _GRAPH_AUDITION
-            n_cand = max(1, _GRAPH_AUDITION)
-            cands, err = [], None
-            try:
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    pack0 = ops.graph_outputs(dev, B, N, n_loc)[0]
-                    ops.set_slots(slots, [x, out, pack0])
-                    for _ in range(2):                       # warm-up: func attributes, head plans, allocator, RCCL's lazy init
-                        whole()
-                torch.cuda.current_stream(dev).wait_stream(side)
-                torch.cuda.synchronize(dev)
-                self.watchdog_wait_s = _watchdog_idle(self.group)
-                for i in range(n_cand):
-                    with _collectives_captured(), ops.capture() as graph:
-                        pack = whole()
-                    cands.append((graph, slots, pack))
-            except RuntimeError as e:
-                err = e
-            if self.world > 1:
-                ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-                if float(ok.item()) < 1.0 and err is None:
-                    err = RuntimeError("a peer rank could not capture the sharded step")
-            if err is not None:
-                raise RuntimeError(str(err))
-            times = []
-            if n_cand > 1:
-                for cand in cands:
-                    ops.set_slots(slots, [x, out, torch.empty_like(cand[2])])
-                    cand[0].replay()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(5):
-                        cand[0].replay()
-                    e1.record()
-                    e1.synchronize()
-                    times.append(e0.elapsed_time(e1) / 5.0)
-                t = torch.tensor(times, dtype=torch.float64, device=dev)
-                if self.world > 1:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                times = [round(float(v), 4) for v in t.tolist()]
-                best = min(range(n_cand), key=lambda i: times[i])
-            else:
-                best = 0
-            self.audition_ms = times
-            ent = st.graphs["whole:" + inference] = cands[best]
-        graph, slots, pack = ent
-        packc = torch.empty_like(pack)
+            like = ops.graph_outputs(dev, B, N, n_loc)[0]
+            packs = ops.SlotRef(slots, 2, like)
+            program = ops.record_program(dev, lambda: step(xs, outs, packs), warmup=2,
+                                         before_warmup=lambda: ops.set_slots(slots, [x, out, like]))
+            ent = st.graphs["whole:" + inference] = (program, slots)
+        program, slots = ent
+        packc = torch.empty_like(program.result)
         ops.set_slots(slots, [x, out, packc])
-        graph.replay()
-        self.launch_form = "one hip-graph incl. the RCCL all-gathers"
-        dense = (self.world - 1) * n_loc * B
-        self.last_exchange = (dense, dense)
+        program.replay()
+        self.launch_form = "one program: %d single-branch hip-graphs + eager RCCL all-gathers" % program.n_graphs
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
         return out, prob, action, nnz
 
@@ -492,7 +342,7 @@ class AgentParallelForward:
             # as in the one-GPU forward, policy conv1..5 ride the policy chain's stream beside the value chain (they were the whole of
             # the sharded path's extra 0.09 ms per step when segment B ran them after the join); segment B keeps the heads
             a = st.run("A", lambda: (eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol],
-                                                          policy_next=(lambda pol: eng.policy_convs(pol, ch_off=0, gate=True), lambda y: y),
+                                                          policy_next=(lambda pol: eng.policy_convs(pol, ch_off=0), lambda y: y),
                                                           value_next=lambda v: eng.value_maps(v, out=st.v_slot, out_own=st.u_own))[1],),
                        use_graph)
             st.pol_y = a[0]

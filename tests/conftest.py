@@ -1,10 +1,6 @@
 import os
 import sys
 
-# before anything can initialise the HIP runtime (multiagentperception_amd/__init__.py says why)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
-
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

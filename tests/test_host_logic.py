@@ -425,31 +425,3 @@ def test_s2_front_fragment_reads_are_bank_conflict_free():
                             addr = (base + br * pitch + bc) * 128 + slot * 16
                             groups.add((addr // 16) % 16)
                         assert len(groups) == 16, (ky, kx, pt, kc, lhi, half)
-
-
-def test_watchdog_idle_is_a_no_op_without_an_rccl_group_and_polls_the_flight_recorder_with_one(monkeypatch):
-    """parallel._watchdog_idle (round 5: the sleep of round 4 replaced by observation): without an RCCL group it returns at once; with
-    one it polls the flight recorder until no entry is un-retired, and raises RuntimeError -- the caller then does NOT capture
-    collectives -- when the recorder is empty (disabled) or stays busy past the timeout."""
-    import time
-    import pytest
-    from multiagentperception_amd import parallel
-    t0 = time.perf_counter()
-    assert parallel._watchdog_idle() == 0.0
-    assert time.perf_counter() - t0 < 0.1
-    monkeypatch.setattr(parallel.dist, "is_initialized", lambda: True)
-    monkeypatch.setattr(parallel.dist, "get_backend", lambda group=None: "nccl")
-    polls = {"n": 0}
-
-    def entries(only_active):
-        polls["n"] += 1                                 # record 7 was issued inside a capture window: never retired, never waited for
-        return [{"retired": polls["n"] >= 4, "record_id": 3}, {"retired": False, "record_id": 7}]
-    monkeypatch.setattr(parallel, "_fr_entries", entries)
-    monkeypatch.setattr(parallel, "_captured_ids", {7})
-    assert parallel._watchdog_idle() >= 0.0 and polls["n"] == 4
-    monkeypatch.setattr(parallel, "_fr_entries", lambda only_active: [])
-    with pytest.raises(RuntimeError, match="cannot prove"):
-        parallel._watchdog_idle()
-    monkeypatch.setattr(parallel, "_fr_entries", lambda only_active: [{"retired": False, "record_id": 1}])
-    with pytest.raises(RuntimeError, match="still listed"):
-        parallel._watchdog_idle(timeout_s=0.05)

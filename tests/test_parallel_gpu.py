@@ -122,15 +122,13 @@ def test_bench_repeats_a_host_stalled_run_once_in_a_fresh_process():
 
 def test_single_rank_rccl_executes_the_sharded_code_path():
     """The multi-rank path -- RCCL process group, in-place all_gather_into_tensor on the buffers the kernels wrote, async work
-    handles, the step captured as one HIP graph with the collectives inside it and RCCL's watchdog thread alive -- executed with ONE rank (RCCL refuses two ranks on
+    handles, the step replayed as one recorded program with the collectives issued between its graphs -- executed with ONE rank (RCCL refuses two ranks on
     one GPU; an 8-GPU node is only available to the driver).  Must print the same kind of line and, being bit-identical code,
     parity must hold."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # (TORCH_FR_BUFFER_SIZE removed: bench.py must switch the flight recorder on by itself, before it creates the process group --
-    #  the one-graph step refuses to capture collectives it cannot prove safe, parallel._watchdog_idle)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCH_FR_BUFFER_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-sharded", "--batch", "2", "--size", "128",
                         "--steps", "5", "--warmup", "2", "--no-pmc"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -139,8 +137,8 @@ def test_single_rank_rccl_executes_the_sharded_code_path():
     out_lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines[-3:]   # ONE JSON line (RCCL's banner goes to stderr)
     d = json.loads(out_lines[0])
-    # round 4: with the nccl backend the rank's whole step -- collectives included -- is ONE captured graph (parallel._softmax_one_graph)
-    assert d["n_gpus"] == 1 and "one hip-graph" in d["config"]["launch"], (d["config"]["launch"], r.stderr.decode()[-1500:])
+    # round 6: the rank's whole step is ONE recorded program -- single-branch graphs, the RCCL all-gathers issued between them (parallel._dense_step)
+    assert d["n_gpus"] == 1 and "one program" in d["config"]["launch"], (d["config"]["launch"], r.stderr.decode()[-1500:])
     assert d["parity"]["logits_rel_l2"] <= 1e-2 and d["parity"]["argmax_agreement"] >= 0.99
 
 
@@ -178,13 +176,13 @@ def _rccl_one_rank_worker(rank, port, N, B, S, seed, out_dir):
 def test_thresholded_modes_through_the_one_graph_sharded_step_equal_the_plain_forward(tmp_path):
     """'activated' / 'argmax_test' across ranks without the handshake's host round trip (parallel._sparse_pays): the dense in-graph
     all-gather + the communication-graph kernel's zero coefficients give the same bits as the plain forward and as the sparse
-    exchange; the step is ONE captured graph with the RCCL collectives inside.  One rank (RCCL refuses two on one GPU)."""
+    exchange; the step is ONE recorded program with the RCCL collectives between its graphs.  One rank (RCCL refuses two on one GPU)."""
     mp.spawn(_rccl_one_rank_worker, args=(_free_port(), 4, 2, 128, 555, str(tmp_path)), nprocs=1, join=True)
     res = torch.load(os.path.join(str(tmp_path), "res.pt"))
     for (mode, sparse), (same, form, exch) in res.items():
         assert same, (mode, sparse, form)
         if mode == "softmax" or not sparse:
-            assert "one hip-graph" in form, (mode, sparse, form)
+            assert "one program" in form, (mode, sparse, form)
         else:
             assert "segments" in form, (mode, sparse, form)
 
