@@ -333,7 +333,7 @@ class TrunkPlan:
             if ds is not None:
                 Hs, Ws = (Hs + 1) // 2, (Ws + 1) // 2
         sq = None if squeezer_out is not None else torch.empty((M, Hs, Ws, self.G * feat), dtype=BF16, device=p.device)
-        L = ops.lanes(p.device)                    # lane 0: the value chain (the caller's stream), lane 1: the policy chain
+        L = ops.lanes(p.device)                    # lane 0 (the caller's stream): the policy chain, lane 1: the value chain
         _stamp(0)
 
         # (Measured and not kept, profiles/r04_s2_front_c64.txt + DESIGN 10: starting the value chain behind block k of the policy chain,
@@ -354,16 +354,22 @@ class TrunkPlan:
                 plans[g][1].run(q, out=sq, out_ch_off=g * feat)
             _stamp(3 + g)
 
+        # Lane 0 (the caller's stream) carries the POLICY chain and everything behind it -- the forward's critical path: front | policy
+        # trunk + policy convs + heads | join + decode stay on ONE stream, ordered by the stream itself; the value chain (which has
+        # ~100 us of slack before the join) takes the cross-stream edges on lane 1.  Round 6, tools/r06/ab.sh, same box interleaved:
+        # value chain on lane 0 1.047-1.051 ms (eager 1.032-1.036), policy chain on lane 0 1.027-1.038 (eager 1.021-1.026).
+        # (Measured and not kept: the policy chain as two row-sliced half-batch chains on two lanes, each launch half the workgroups --
+        # eager 1.058 vs 1.034, recorded program 1.35 ms: three chains contend for the same slots and the program's third stream shares a
+        # hardware pipe.  profiles/r05_policy_tail.txt: the policy chain's launches at s_setprio 3 make BOTH chains slower.)
+        pol_map = None if policy_next is None else (sq if squeezer_out is None else squeezer_out[1])
         state = None
         with L.on(1, after=(0,)):
-            # (Measured and not kept, profiles/r05_policy_tail.txt: the policy chain's conv launches at s_setprio 3 -- it is the critical
-            # path, the value chain has ~100 us of slack -- make BOTH chains slower: 0.992-0.999 -> 1.010-1.016 ms.)
-            chain(1)
-            if policy_next is not None:            # the policy chain goes straight on (policy convs) beside the value chain
-                state = policy_next[0](sq if squeezer_out is None else squeezer_out[1])
-        chain(0)
-        vres = value_next(sq if squeezer_out is None else squeezer_out[0]) if value_next is not None else None
-        _stamp(26)
+            chain(0)
+            vres = value_next(sq if squeezer_out is None else squeezer_out[0]) if value_next is not None else None
+            _stamp(26)
+        chain(1)
+        if policy_next is not None:                # the policy chain goes straight on (policy convs, heads) beside the value chain
+            state = policy_next[0](pol_map)
         L.join(1)
         _stamp(5)
         extra = policy_next[1](state) if policy_next is not None else None

@@ -169,10 +169,10 @@ class AgentParallelForward:
 
     Per step and rank (dense exchange: 'softmax', and the thresholded modes below _sparse_pays' limit) -- _dense_step:
         stem (reads the caller's frames through a pointer slot) -> layer1 (both trunks) -> layer2.0's front -> fork
-          lane 0, value chain : layer2..4, squeezer, decoder conv0 on the local value maps (U, by linearity: engine.DecoderPlan.value_maps,
+          lane 1, value chain : layer2..4, squeezer, decoder conv0 on the local value maps (U, by linearity: engine.DecoderPlan.value_maps,
                                 written straight into this rank's rows of the gather buffer), in-place RCCL all-gather of U -- issued from
                                 the value chain, so it travels under the policy chain's tail
-          lane 1, policy chain: layer2..4, squeezer, policy conv1..5, heads (projected keys into this rank's rows), all-gather of K
+          lane 0, policy chain: layer2..4, squeezer, policy conv1..5, heads (projected keys into this rank's rows), all-gather of K
         join -> graph columns of the local queries + fusion of the U maps + bias + ReLU -> decoder's last conv -> x32 upsample into the
         caller-owned logits (pointer slot) -> packed prob / action / nnz into the caller-owned copy.
     With model.use_hip_graph the step is ONE recorded program (ops.record_program): ~45 kernel launches become a handful of
@@ -270,18 +270,18 @@ class AgentParallelForward:
             eng.trunk.stem(xs, n_loc, out=st.s0)
 
             def value_tail(v):
-                # U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K gather
-                # (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel under
-                # the policy tail.  The K gather is issued from the policy chain's lane, behind the heads.
+                # (lane 1) U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K
+                # gather (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel
+                # under the policy tail.  after_stem hands the value chain its launches first, the policy chain's second.
                 u = eng.value_maps(v, out=st.v_slot, out_own=st.u_own)
                 L.eager(lambda: works.append(_gather_inplace(st.v_all, self.rank, rows, self.group)))
-                with L.on(1):
-                    L.eager(lambda: works.append(_gather_inplace(st.k_all, self.rank, rows, self.group)))
                 return u
 
             def policy_tail(pol):
+                # (lane 0)
                 y = eng.policy_convs(pol, ch_off=0)
                 eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
+                L.eager(lambda: works.append(_gather_inplace(st.k_all, self.rank, rows, self.group)))
                 return y
 
             eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
