@@ -132,6 +132,13 @@ int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x
                           const float* scale, const float* shift,
                           const uint16_t* residual, int relu,
                           uint16_t* y, int y_cstride, long long y_group_stride, int form, w2c_stream_t stream);
+/* w2c_conv3x3_wreg_f32out: the default form of the entry point above writing an f32 NHWC tensor (y_cstride / y_group_stride in f32
+ * elements), no residual -- the decoder's first conv `simple_decoder` backbone.py:150 taken through the fusion agent.py:276-284 by
+ * linearity (U = conv0 without bias / ReLU of every agent's value map).  Shapes for which w2c_conv3x3_wreg_supported() is 0: W2C_E_ARG. */
+int w2c_conv3x3_wreg_f32out(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                            const uint16_t* wfrag, int Cout, int groups,
+                            const float* scale, const float* shift, int relu,
+                            float* y, int y_cstride, long long y_group_stride, w2c_stream_t stream);
 
 /* Split-K form of K2 for the tail layers (policy_net4 conv3..5 agent.py:128-132, simple_decoder's last conv
  * backbone.py:152): few output tiles under a long weight-streaming K loop.  `ksplit` workgroups share a tile, each
@@ -219,21 +226,6 @@ int w2c_conv_s2_front_c64(const uint16_t* x, int M, int H, int W, int x_cstride,
  * getenv().  w2c_set_option changes a switch at run time (returns W2C_E_ARG for an unknown name), w2c_get_option reads it (-1 unknown). */
 int w2c_set_option(const char* name, int value);
 int w2c_get_option(const char* name);
-
-/* ---- a whole stride-1 BasicBlock with Cin = Cout = 64 (layer1 of the third-party resnet18, backbone.py:63-69) in ONE launch:
- *   y = relu(bn2(conv2 3x3 (relu(bn1(conv1 3x3 (x))))) + x)
- * The intermediate map never leaves the CU (csrc/conv_block.hip: flattened row strips, x and t in LDS rings, conv1 and conv2 on
- * different waves with their weights in registers).  Bit-identical to the two w2c_conv_igemm_bf16 launches it replaces.
- * x, y : bf16 NHWC [M][H][W][x_cstride | y_cstride], group g in channels [64 g, 64 g + 64); x != y (halo rows are re-read).
- * w1, w2 : [groups][64][9][64] bf16 packed like every conv here; scale / shift : folded eval BatchNorm, [groups*64] f32.
- * W % 8 == 0 and (W <= 128 or W % 128 == 0); tensors < 2 GiB.  max_workgroups <= 0: one workgroup per CU (tests pass small
- * values to exercise multi-strip workgroups). */
-/* debug: the next w2c_conv_block_c64 call of this thread writes per-wave phase cycle sums to buf (tools/block_phases.py) */
-int w2c_debug_block_phases(void* buf);
-int w2c_conv_block_c64(const uint16_t* x, int M, int H, int W, int x_cstride,
-                       const uint16_t* w1, const float* scale1, const float* shift1,
-                       const uint16_t* w2, const float* scale2, const float* shift2,
-                       int groups, uint16_t* y, int y_cstride, int max_workgroups, w2c_stream_t stream);
 
 /* ---- SURVEY 8f rank 3 (training backward, first stage): gradients of the path's 3x3 / 1x1 convolutions
  * (nn.Conv2d under loss.backward(), trainer.py:669-673).

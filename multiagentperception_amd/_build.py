@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libw2c_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_block.hip", "conv_wgrad.hip", "bn_train.hip", "stem.hip", "stem_train.hip", "comm_attn.hip", "upsample.hip", "loss.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "bn_train.hip", "stem.hip", "stem_train.hip", "comm_attn.hip", "upsample.hip", "loss.hip"]
 
 
 def _hipcc():

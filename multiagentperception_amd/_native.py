@@ -34,6 +34,7 @@ SIGNATURES = {
     "w2c_pack_wfrag_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "w2c_conv3x3_wreg_supported": [_i, _i, _i, _i],
     "w2c_conv3x3_wreg_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _vp],
+    "w2c_conv3x3_wreg_f32out": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _ll, _vp],
     "w2c_debug_conv_timeline": [_vp],
     "w2c_debug_stamp": [_vp, _vp],
     "w2c_debug_install_crash_backtrace": [_i],
@@ -48,8 +49,6 @@ SIGNATURES = {
     "w2c_conv_s2_front_c64": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _vp, _i, _ll, _vp],
     "w2c_set_option": [_c.c_char_p, _i],
     "w2c_get_option": [_c.c_char_p],
-    "w2c_debug_block_phases": [_vp],
-    "w2c_conv_block_c64": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "w2c_conv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
     "w2c_conv_wgrad_bf16": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _ll, _vp],
     "w2c_conv_wgrad_bf16_oihw": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _ll, _vp],

@@ -2118,8 +2118,13 @@ __global__ __launch_bounds__(MAXT) void conv_inwg_splitk_kernel(ConvArgs p) {
             *reinterpret_cast<f32x4_t*>(mine + (i * 32 + l31) * CLD + eg * 8 + lhi * 4) =
                 f32x4_t{acc[i][eg * 4], acc[i][eg * 4 + 1], acc[i][eg * 4 + 2], acc[i][eg * 4 + 3]};
     __syncthreads();
+    // read-out item id -> (row r = id % BM_, channel group cg = id / BM_): a wave's lanes walk consecutive ROWS of one channel group,
+    // so the 16 lanes ds_read_b128 services together read 16-byte runs at 144-byte (CLD floats) steps -- 36 r mod 64 dwords is a
+    // bijection on any 16 rows that differ mod 16: every bank once.  (Rounds 3-5 mapped r = id / CG, cg = id % CG: four lanes per row,
+    // rows {0, 3, 5, 6} of a service group collide pairwise -- SQ_LDS_BANK_CONFLICT 25 % of the LDS cycles of these launches.)  The
+    // order of the additions per output is unchanged: same bits.
     for (int id = tid; id < BM_ * CG; id += (int)blockDim.x) {      // (fewer than 4 splits: fewer threads than read-out items)
-        const int r = id / CG, cg = id - r * CG;
+        const int cg = id / BM_, r = id - cg * BM_;
         const int gr = m0 + r;
         if (gr >= p.rows) continue;
         const float* sp = part + r * CLD + cg * 8;
@@ -2270,6 +2275,7 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 83: return launch_wreg<1, 2>(a, groups, s);
         case 93: return launch_wreg<1, 4, 0, 4>(a, groups, s);   // 81 with the weights 4 / 2 K-steps ahead instead of 8
         case 94: return launch_wreg<1, 4, 0, 2>(a, groups, s);
+        case 193: return launch_wreg<1, 4, 0, 4, 2, true>(a, groups, s);      // 93 writing f32 (w2c_conv3x3_wreg_f32out)
         // (round 4, removed in round 5: 32 channels per wave -- 8 waves on the same workgroup tile, bit-identical -- for the small launches:
         //  +-8 % alone, slower in every forward (profiles/r04_rank_shapes.txt): those launches are not short of waves)
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
@@ -2475,6 +2481,25 @@ extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int
     if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94 && form != 54) return W2C_E_ARG;
     w2c_clear_error();
     return launch_variant(form, a, groups, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The default form (93) with an f32 output tensor and no residual: the decoder's first conv on every agent's value map (U = conv0 without
+// bias / ReLU, fused after the communication graph by linearity).  Same K groups and reduction order as w2c_conv3x3_wreg_bf16: the f32
+// values are what that entry point rounds to bf16.
+extern "C" int w2c_conv3x3_wreg_f32out(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
+                                       const uint16_t* wfrag, int Cout, int groups,
+                                       const float* scale, const float* shift, int relu,
+                                       float* y, int y_cstride, long long y_group_stride, w2c_stream_t stream) {
+    ConvArgs a;
+    const int rc = fill_args(a, x, M, H, W, Cin, x_cstride, wfrag, Cout, 3, 1, groups, scale, shift, nullptr, relu, y, y_cstride, 1,
+                             /*zero_page=*/x, y_group_stride);
+    if (rc != W2C_OK) return rc;
+    if (wreg_form(H, W, Cin, Cout) != 93) return W2C_E_ARG;
+    if ((size_t)M * H * W * y_cstride >= (1ull << 31) || y_group_stride < 0 ||
+        (unsigned long long)(groups - 1) * (unsigned long long)(y_group_stride ? y_group_stride : Cout) + (size_t)M * H * W * y_cstride >= (1ull << 31))
+        return W2C_E_ARG;
+    w2c_clear_error();
+    return launch_variant(193, a, groups, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,

@@ -28,7 +28,9 @@
 // NB = 32-channel blocks per wave (2: the wave tile above; 1: 128 pixels x 32 channels -- twice the waves on the same workgroup tiles for
 // launches that cannot fill the chip's wave slots (M <= 20 tail convs, a rank's share of a sharded batch): one wave per SIMD hides none of
 // its weight-load and LDS latencies.  Same K groups, same reduction order: bit-identical to NB = 2.
-template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
+// F32OUT: the output tensor is f32 (the decoder's first conv taken through the fusion by linearity: U = conv0_nobias(V), engine.DecoderPlan);
+// a lane stores its two channel quads as they sit in the accumulators (two 16-byte stores 8 channels apart): no pack, no half-wave swap.
+template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2, bool F32OUT = false>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
 __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PW = 18, NP = 180, NPIECE = 23;  // patch: 10 x 18 pixels, 128 B each, DMA'd in 1 KB pieces of 8 pixels
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
 #pragma unroll
     for (int ii = 0; ii < CNT; ++ii) {
         const int oy = y0 + blkoff[ii] / (PW * 128) + (l31 >> 4), ox = x0 + pc0;
-        eoff[ii] = (unsigned)((((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.ygs + n0 + lhi * 8);
+        eoff[ii] = (unsigned)((((size_t)img * p.H + oy) * p.W + ox) * p.ycs + (size_t)g * p.ygs + n0 + lhi * (F32OUT ? 4 : 8));
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int ii = 0; ii < CNT; ++ii)
-                rres[ii][j][m] = p.res ? *reinterpret_cast<const uint4*>(p.res + eoff[ii] + j * 32 + m * 16) : make_uint4(0, 0, 0, 0);
+                rres[ii][j][m] = (!F32OUT && p.res) ? *reinterpret_cast<const uint4*>(p.res + eoff[ii] + j * 32 + m * 16) : make_uint4(0, 0, 0, 0);
     pipeline_barrier();                              // every wave is done with the patch buffers: LDS is reused below
     dbg_stamp(p, 2);
 
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
                     const int i = ii;
                     f32x4_t v0 = f32x4_t{acc[i][j][m * 8], acc[i][j][m * 8 + 1], acc[i][j][m * 8 + 2], acc[i][j][m * 8 + 3]} * sc0 + sh0;
                     f32x4_t v1 = f32x4_t{acc[i][j][m * 8 + 4], acc[i][j][m * 8 + 5], acc[i][j][m * 8 + 6], acc[i][j][m * 8 + 7]} * sc1 + sh1;
-                    if (p.res) {
+                    if (!F32OUT && p.res) {
                         // the lane's 16 residual bytes are in the STORE layout; the same half-wave swap (it is its own inverse)
                         // brings them into the accumulator layout (two channel quads 8 channels apart)
                         const uint4 r = rres[ii][j][m];
@@ -338,6 +340,12 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    }
+                    if constexpr (F32OUT) {
+                        float* const yo = reinterpret_cast<float*>(p.y) + eoff[ii] + j * 32 + m * 16;
+                        *reinterpret_cast<f32x4_t*>(yo) = v0;
+                        *reinterpret_cast<f32x4_t*>(yo + 8) = v1;
+                        continue;
                     }
                     const uint32_t a0 = pack_bf16x2(v0[0], v0[1]), a1 = pack_bf16x2(v0[2], v0[3]);
                     const uint32_t b0 = pack_bf16x2(v1[0], v1[1]), b1 = pack_bf16x2(v1[2], v1[3]);
@@ -366,10 +374,10 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
 #endif
 }
 
-template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2>
+template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2, bool F32OUT = false>
 int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
-    if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % (NN * 32 * NB) != 0 || a.H % 8 != 0 || a.W % 16 != 0 || a.y_f32 || a.y8 ||
-        !a.y || a.ws)
+    if (a.ks != 3 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % (NN * 32 * NB) != 0 || a.H % 8 != 0 || a.W % 16 != 0 || (a.y_f32 != 0) != F32OUT || a.y8 ||
+        !a.y || a.ws || (F32OUT && a.res))
         return W2C_E_ARG;
     a.ntm = a.M * (a.H / 8) * (a.W / 16);
     a.ntn = a.Cout / (NN * 32 * NB);
@@ -381,12 +389,12 @@ int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel<NN, KS, ABL, DW, NB, F32OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int xcd2d_mode = w2c_option(W2C_OPT_XCD2D);
     const long wbytes = (long)a.Cout * 9 * a.Cin * 2;
     a.xcd2d = (xcd2d_mode == 2 || (xcd2d_mode == 1 && wbytes >= (2 << 20))) && !(a.ntm & 1) && !(a.ntn & 3);
-    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW, NB>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_wreg_kernel<NN, KS, ABL, DW, NB, F32OUT>), dim3(a.ntm * a.ntn, groups), dim3(64 * NN * KS), lds, s, a);
     return w2c_launch_status();
 }

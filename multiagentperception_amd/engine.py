@@ -111,6 +111,10 @@ class ConvPlan:
         if out_groups is not None and len(out_groups) > 1:
             span = out_groups[-1].data_ptr() - out_groups[0].data_ptr()
             far = span < 0 or span // 2 + out_groups[0].numel() >= (1 << 31)
+        if (self.wfrag is not None and out_f32 and self.groups == 1 and residual is None and out_groups is None
+                and ops.conv3x3_wreg_supported(x.shape[1], x.shape[2], self.cin, self.cout)):
+            return ops.conv3x3_wreg_f32(x, x_ch_off, self.cin, self.wfrag, self.cout, self.scale, self.shift, relu=self.relu, out=out,
+                                        out_ch_off=out_ch_off)
         if (self.wfrag is not None and not out_f32 and not far
                 and ops.conv3x3_wreg_supported(x.shape[1], x.shape[2], self.cin, self.cout)):
             return ops.conv3x3_wreg(x, x_ch_off, self.cin, self.wfrag, self.cout, self.groups, self.scale, self.shift,
@@ -589,8 +593,9 @@ class DecoderPlan:
                 conv = torch.nn.Conv2d(feat, cout, 3, padding=1, bias=False).to(w.device)
                 with torch.no_grad():
                     conv.weight.copy_(w[:, i * feat:(i + 1) * feat])
-                part = ConvPlan([conv], relu=False)
-                part.wfrag = None                                   # f32 output: the ring kernels' epilogue
+                part = ConvPlan([conv], relu=False)                 # (f32 output: w2c_conv3x3_wreg_f32out where the shape has a wreg form)
+                if os.environ.get("W2C_U_RING"):                    # A/B: the ring kernels' f32 epilogue (rounds 4-5)
+                    part.wfrag = None
                 self.cu_parts.append(part)
             self.cu = self.cu_parts[0]
             self.cu_bias = pred[0].bias.detach().float().contiguous()

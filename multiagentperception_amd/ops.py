@@ -714,6 +714,36 @@ def conv3x3_wreg_supported(H, W, cin, cout):
     return bool(_native.lib().w2c_conv3x3_wreg_supported(int(H), int(W), int(cin), int(cout)))
 
 
+def conv3x3_wreg_f32(x, x_ch_off, cin, wfrag, cout, scale, shift, relu=False, out=None, out_ch_off=0):
+    """w2c_conv3x3_wreg_f32out: the weights-to-registers kernel (default form) writing an f32 NHWC tensor, one group, no residual
+    (the decoder's first conv on the value maps, engine.DecoderPlan.value_maps).  out: f32 [M,H,W,>=out_ch_off+cout] or None."""
+    dev = _need_gpu(x, wfrag, scale, shift, out)
+    M, H, W, xcs = x.shape
+    if out is None:
+        out = torch.empty((M, H, W, cout), dtype=torch.float32, device=dev)
+    ocs = out.shape[3]
+    if tuple(out.shape[:3]) != (M, H, W) or out.dtype != torch.float32 or out_ch_off % 4 or out_ch_off + cout > ocs:
+        raise W2CError("conv3x3_wreg_f32: out must be f32 [M,H,W,>= out_ch_off + cout]")
+    if x_ch_off < 0 or x_ch_off + cin > xcs:
+        raise W2CError("conv3x3_wreg_f32: channel window outside the tensor")
+    per_img = max(H * W * xcs * 2, H * W * ocs * 4)
+    if M * per_img > _MAX_X_BYTES:
+        step = max(1, _MAX_X_BYTES // per_img)
+        for lo in range(0, M, step):
+            conv3x3_wreg_f32(x[lo:lo + step], x_ch_off, cin, wfrag, cout, scale, shift, relu, out[lo:lo + step], out_ch_off)
+        return out
+    timer = getattr(_tls, "conv_timer", None)
+    tok = timer.begin(dev) if timer is not None else None
+    with torch.cuda.device(dev):
+        check(_native.lib().w2c_conv3x3_wreg_f32out(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(wfrag), cout, 1, _p(scale), _p(shift),
+                                                    1 if relu else 0, out.data_ptr() + 4 * out_ch_off, ocs, 0, _stream(dev)),
+              "w2c_conv3x3_wreg_f32out")
+    if timer is not None:
+        timer.end(tok, dev, 2.0 * M * H * W * cout * 9 * cin, (M * H * W, cin, cout, 3, 1, 1),
+                  M * H * W * cin * 2 + M * H * W * cout * 4 + cout * 9 * cin * 2)
+    return out
+
+
 def conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, residual=None, relu=True, out=None, out_cstride=None,
                  form=0, out_ch_off=0, _gstride=0, out_groups=None):
     """w2c_conv3x3_wreg_bf16: 3x3 / stride 1 / pad 1, bf16 NHWC in and out; `wfrag` from pack_wfrag_device.  Same tensor
@@ -953,38 +983,6 @@ def conv_s2_front_c64(x, x_ch_off, w3frag, scale3, shift3, w1frag, scale1, shift
         nbytes = M * H * W * 64 * groups * 2 + M * Ho * Wo * 128 * groups * 4 + groups * 128 * 10 * 64 * 2
         timer.end(tok, dev, flops, (M * Ho * Wo, 64, 128, "3+1", 2, groups), nbytes)
     return t16, idt
-
-
-def conv_block_c64(x, w1, scale1, shift1, w2, scale2, shift2, groups, out=None, max_workgroups=0):
-    """A whole 64-channel stride-1 BasicBlock in one launch (include/w2c_hip.h w2c_conv_block_c64):
-    y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).  x bf16 NHWC [M,H,W,cs], group g in channels [64g, 64g+64);
-    w1 / w2 [G,64,576] bf16 packed."""
-    dev = _need_gpu(x, w1, scale1, shift1, w2, scale2, shift2, out)
-    M, H, W, xcs = x.shape
-    if x.dtype != BF16 or w1.dtype != BF16 or w2.dtype != BF16 or w1.shape != (groups, 64, 576) or w2.shape != (groups, 64, 576):
-        raise W2CError("conv_block_c64: bf16 x and [G,64,576] bf16 packed weights expected")
-    if xcs < groups * 64:
-        raise W2CError("conv_block_c64: channels outside the tensor")
-    if out is None:
-        out = torch.empty((M, H, W, groups * 64), dtype=BF16, device=dev)
-    if out.dtype != BF16 or out.shape[:3] != x.shape[:3] or out.shape[3] < groups * 64 or out.data_ptr() == x.data_ptr():
-        raise W2CError("conv_block_c64: out must be a different bf16 NHWC tensor of the same spatial shape")
-    timer = getattr(_tls, "conv_timer", None)
-    if timer is not None and timer.spans:
-        timer = None                               # (csrc/conv_block.hip takes no span pointer)
-    tok = timer.begin(dev) if timer is not None else None
-    with torch.cuda.device(dev):
-        check(_native.lib().w2c_conv_block_c64(_p(x), M, H, W, xcs, _p(w1), _p(scale1), _p(shift1), _p(w2), _p(scale2), _p(shift2),
-                                               groups, _p(out), out.shape[3], int(max_workgroups), _stream(dev)),
-              "w2c_conv_block_c64")
-    if timer is not None:
-        flops = 2.0 * 2.0 * M * H * W * 64 * 576 * groups
-        nbytes = 2 * M * H * W * 64 * groups * 2 + 2 * groups * 64 * 576 * 2
-        timer.end(tok, dev, flops, (M * H * W, 64, 64, "3,3 block", 1, groups), nbytes)
-    return out
-
-
-_wgrad_ws = {}
 
 
 def stem_conv7x7_train(x_nhwc3, w_packed, out=None):

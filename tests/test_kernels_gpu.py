@@ -928,78 +928,6 @@ def test_pingpong_stem_is_race_free_over_repeated_launches(wgs, lib_option):
         assert torch.equal(got, ref)
 
 
-# ---- fused layer1 BasicBlock (csrc/conv_block.hip) ------------------------------------------------------------------------------
-def _block_inputs(M, H, W, G, cs, seed):
-    gen = torch.Generator().manual_seed(seed)
-    dev = _dev()
-    x = torch.zeros(M, H, W, cs, dtype=BF16)
-    x[..., :G * 64] = torch.randn(M, H, W, G * 64, generator=gen).to(BF16)
-    if cs > G * 64:
-        x[..., G * 64:] = 7.0                          # channels that do not belong to the block: must not be read
-    w1 = (torch.randn(G, 64, 576, generator=gen) * (2.0 / 576) ** 0.5).to(BF16)
-    w2 = (torch.randn(G, 64, 576, generator=gen) * (2.0 / 576) ** 0.5).to(BF16)
-    s1 = torch.rand(G * 64, generator=gen) + 0.5
-    s1[::7] *= -1.0                                     # negative BN scales too
-    b1 = torch.randn(G * 64, generator=gen) * 0.3
-    s2 = torch.rand(G * 64, generator=gen) + 0.5
-    b2 = torch.randn(G * 64, generator=gen) * 0.3
-    return [t.to(dev) for t in (x, w1, s1, b1, w2, s2, b2)]
-
-
-def _block_two_launches(x, w1, s1, b1, w2, s2, b2, G):
-    from multiagentperception_amd import ops
-    t = ops.conv_igemm(x, 0, 64, w1, 64, 3, 1, G, s1, b1, relu=True)
-    xr = x if x.shape[3] == G * 64 else x[..., :G * 64].contiguous()
-    return ops.conv_igemm(t, 0, 64, w2, 64, 3, 1, G, s2, b2, residual=xr, relu=True)
-
-
-@pytest.mark.parametrize("M,H,W,G,cs,wgs", [
-    (2, 32, 32, 2, 128, 0),       # cfg-1-sized layer1 map, both trunks
-    (3, 16, 16, 1, 64, 0),        # Single_agent
-    (1, 24, 64, 2, 128, 0),
-    (2, 40, 128, 2, 128, 0),      # full-width strips (P = 136, the cfg-2 geometry)
-    (1, 12, 256, 1, 64, 0),       # two column strips per image (the cfg-4 geometry)
-    (5, 32, 32, 2, 128, 3),       # 3 workgroups walk 10 units: several strips and BOTH groups per workgroup (weight reload)
-    (2, 32, 32, 2, 192, 0),       # wider channel stride than the block uses
-    (1, 8, 8, 1, 64, 0),
-])
-def test_fused_basic_block_is_bit_identical_to_its_two_conv_launches(M, H, W, G, cs, wgs):
-    """y = relu(bn2(conv2(relu(bn1(conv1 x)))) + x) in one launch == the two w2c_conv_igemm_bf16 launches (torch.equal), and
-    both within 2e-2 of an f32 evaluation with the intermediate rounded to bf16 where the two-launch form stores it."""
-    from multiagentperception_amd import ops
-    x, w1, s1, b1, w2, s2, b2 = _block_inputs(M, H, W, G, cs, seed=M * 1000 + H + W + G)
-    ref = _block_two_launches(x, w1, s1, b1, w2, s2, b2, G)
-    y = ops.conv_block_c64(x, w1, s1, b1, w2, s2, b2, G, max_workgroups=wgs)
-    torch.cuda.synchronize()
-    assert torch.isfinite(y.float()).all()
-    assert torch.equal(y, ref), "max abs diff %g" % float((y.float() - ref.float()).abs().max())
-    # f32 reference on CPU
-    xc = x[..., :G * 64].float().cpu().permute(0, 3, 1, 2)
-    outs = []
-    for g in range(G):
-        xg = xc[:, g * 64:(g + 1) * 64]
-        wa = w1[g].float().cpu().reshape(64, 3, 3, 64).permute(0, 3, 1, 2)
-        wb = w2[g].float().cpu().reshape(64, 3, 3, 64).permute(0, 3, 1, 2)
-        sl = slice(g * 64, (g + 1) * 64)
-        t = F.relu(F.conv2d(xg, wa, padding=1) * s1.cpu()[sl].view(1, -1, 1, 1) + b1.cpu()[sl].view(1, -1, 1, 1))
-        t = t.to(BF16).float()
-        o = F.relu(F.conv2d(t, wb, padding=1) * s2.cpu()[sl].view(1, -1, 1, 1) + b2.cpu()[sl].view(1, -1, 1, 1) + xg)
-        outs.append(o)
-    want = torch.cat(outs, 1).permute(0, 2, 3, 1)
-    got = y.float().cpu()
-    assert (got - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
-
-
-def test_fused_basic_block_is_race_free_at_full_size():
-    """cfg-2 layer1 shape (one strip per CU, 49 lock-steps each): 6 launches give the same bits."""
-    from multiagentperception_amd import ops
-    x, w1, s1, b1, w2, s2, b2 = _block_inputs(20, 128, 128, 2, 128, seed=5)
-    ref = _block_two_launches(x, w1, s1, b1, w2, s2, b2, 2)
-    for _ in range(6):
-        y = ops.conv_block_c64(x, w1, s1, b1, w2, s2, b2, 2)
-        assert torch.equal(y, ref)
-
-
 @pytest.mark.parametrize("who,mode,B,N,has_q,q_lo,q_n", [
     (False, "softmax", 4, 5, True, 0, 5), (False, "activated", 4, 5, True, 0, 5), (False, "argmax_test", 2, 6, True, 0, 6),
     (True, "softmax", 4, 5, False, 0, 5), (True, "activated", 3, 5, True, 0, 5),
@@ -1149,6 +1077,34 @@ def test_conv3x3_wreg_matches_fp32_conv(case):
                         residual=None if res_dev is None else res_dev[..., :G * cout].contiguous(), relu=relu)
     d = (y[..., :G * cout].float() - y0.float()).abs()
     assert float((d / (y0.float().abs() + 1.0)).max()) <= 2 ** -7
+
+
+@pytest.mark.parametrize("M,H,W,cin,cout,relu,ocs,off", [(5, 16, 16, 512, 256, False, 256, 0), (3, 8, 16, 256, 64, True, 136, 8),
+                                                         (2, 16, 32, 512, 256, False, 512, 256)])
+def test_conv3x3_wreg_f32_output_rounds_to_the_bf16_form(M, H, W, cin, cout, relu, ocs, off):
+    """w2c_conv3x3_wreg_f32out (round 6: the decoder's first conv on the value maps, U = conv0 without bias): the same K groups and
+    reduction order as the default bf16 form -- its f32 values ROUND to that form's bf16 output bit for bit --, within f32 summation
+    order of an fp32 conv of the same bf16 operands, independent of the image count, and nothing outside the channel window is written."""
+    from multiagentperception_amd import ops
+    case = (93, M, H, W, cin, cout, 1, False, relu, 0, 0)
+    xs, ws, scale, shift, _, x_dev, w_dev, _ = _wreg_setup(case, 4242 + cin + cout)
+    wfrag = ops.pack_wfrag_device(w_dev, cin)
+    sc, sh = scale.to(_dev()), shift.to(_dev())
+    out = torch.full((M, H, W, ocs), 7.0, dtype=torch.float32, device=_dev())
+    y = ops.conv3x3_wreg_f32(x_dev, 0, cin, wfrag, cout, sc, sh, relu=relu, out=out, out_ch_off=off)
+    y16 = ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, relu=relu)
+    torch.cuda.synchronize()
+    win = y[..., off:off + cout]
+    assert torch.equal(win.to(BF16), y16)
+    ref = F.conv2d(xs[0], ws[0], None, stride=1, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    np.testing.assert_allclose(win.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-5)
+    mask = torch.ones(ocs, dtype=torch.bool)
+    mask[off:off + cout] = False
+    assert bool((y[..., mask.to(_dev())] == 7.0).all()), "channels outside the written window were touched"
+    one = ops.conv3x3_wreg_f32(x_dev[M - 1:].contiguous(), 0, cin, wfrag, cout, sc, sh, relu=relu)
+    assert torch.equal(one[0], win[M - 1])
 
 
 def test_conv3x3_wreg_is_independent_of_the_image_count_and_repeatable():
