@@ -35,14 +35,6 @@ def _fold_bn(bn, conv_bias=None):
     return scale, shift
 
 
-_USE_WREG = not os.environ.get('W2C_NO_WREG')      # A/B switch, read once
-# the remaining A/B switches, read once at import (never on the launch path)
-_NO_SPLITK = bool(os.environ.get('W2C_NO_SPLITK'))
-_NO_DUAL = bool(os.environ.get('W2C_NO_DUAL'))
-_FP8_SERIAL = bool(os.environ.get('W2C_FP8_SERIAL'))
-_NO_TAIL_OVERLAP = bool(os.environ.get('W2C_NO_TAIL_OVERLAP'))
-_HEAD_MFMA = os.environ.get('W2C_HEAD_MFMA', '1') != '0'   # fc.0 of the heads on the f32 matrix pipe (split-K partials)
-
 
 def _pack_w(conv_weight):
     """[Cout, Cin, kh, kw] f32 -> [Cout, kh*kw*Cin] bf16 (tap-major, channel-minor K)."""
@@ -87,13 +79,13 @@ class ConvPlan:
         # deep 3x3 / stride-1 layers also keep a fragment-ordered copy of their weights for the weights-to-registers kernel
         # (w2c_conv3x3_wreg_bf16); whether a call uses it is the library's decision, from the layer geometry only
         self.wfrag = None
-        if (_USE_WREG and self.ksize == 3 and self.stride == 1 and self.cin % 64 == 0 and self.cout % 64 == 0 and self.w.is_cuda
+        if (self.ksize == 3 and self.stride == 1 and self.cin % 64 == 0 and self.cout % 64 == 0 and self.w.is_cuda
                 and ops.conv3x3_wreg_supported(8, 16, self.cin, self.cout)):
             self.wfrag = ops.pack_wfrag_device(self.w, self.cin)
         # the two convs of a stride-2 block front keep fragment-ordered copies for w2c_conv_s2_block_wreg (same rule: the library
         # decides from the geometry, _block_front asks it)
         self.wfrag_s2 = None
-        if (_USE_WREG and self.stride == 2 and self.cin % 64 == 0 and self.cin <= 256 and self.cout % 64 == 0 and self.w.is_cuda
+        if (self.stride == 2 and self.cin % 64 == 0 and self.cin <= 256 and self.cout % 64 == 0 and self.w.is_cuda
                 and ops.conv_s2_block_wreg_supported(16, 32, self.cin, self.cout)):
             if self.ksize == 3:
                 self.wfrag_s2 = ops.pack_wfrag_device(self.w, self.cin)
@@ -102,7 +94,7 @@ class ConvPlan:
 
         # layer2.0's two convs (64 -> 128, stride 2) keep fragment-ordered copies for w2c_conv_s2_front_c64 (conv_s2regh.inl)
         self.wfrag_c64 = None
-        if (_USE_WREG and self.stride == 2 and self.cin == 64 and self.cout == 128 and self.w.is_cuda
+        if (self.stride == 2 and self.cin == 64 and self.cout == 128 and self.w.is_cuda
                 and ops.conv_s2_front_c64_supported(16, 16, 64, 128)):
             self.wfrag_c64 = ops.pack_wfrag_device(self.w, 64) if self.ksize == 3 else ops.pack_w1frag(self.w, 64) if self.ksize == 1 else None
 
@@ -122,7 +114,7 @@ class ConvPlan:
         # ksplit=0: the library splits K across workgroups where a layer has too few output tiles to fill the chip
         return ops.conv_igemm(x, x_ch_off, self.cin, self.w, self.cout, self.ksize, self.stride, self.groups,
                               self.scale, self.shift, residual=residual, relu=self.relu, out_f32=out_f32,
-                              ksplit=None if _NO_SPLITK else 0, out_groups=out_groups, out=out,
+                              ksplit=0, out_groups=out_groups, out=out,
                               out_ch_off=out_ch_off)
 
 
@@ -169,8 +161,7 @@ def _front_c64_ok(c1, ds, x):
 
 def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
     """conv1 (+ the 1x1/s2 downsample of a stride-2 block) of a BasicBlock on x -> (t, identity).  Stride-2 blocks run
-    both convs as ONE launch (w2c_conv_s2_block: the 3x3's centre tap IS the 1x1's input); W2C_NO_DUAL=1 keeps the two
-    separate launches (bit-identical, for A/B timing).  With t_fp8_scale, t is the fp8 tensor (Fp8ConvPlans)."""
+    both convs as ONE launch (w2c_conv_s2_block: the 3x3's centre tap IS the 1x1's input).  With t_fp8_scale, t is the fp8 tensor (Fp8ConvPlans)."""
     f8 = t_fp8_scale is not None
     if ds is None:
         if f8:
@@ -181,7 +172,7 @@ def _block_front(c1, ds, x, x_ch_off=0, t_fp8_scale=None):
     # kernel when the map is large enough to pay for its second accumulator set (>= 16 k output pixels).  Same bits either way.
     Ho, Wo = (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2
     patch_ok = Ho % 8 == 0 and Wo % 16 == 0 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
-    if _NO_DUAL or not (patch_ok or x.shape[0] * Ho * Wo >= 16384):
+    if not (patch_ok or x.shape[0] * Ho * Wo >= 16384):
         if f8:
             return (c1.run(x, x_ch_off=x_ch_off, out_bf16=False, out_fp8_scale=t_fp8_scale)[1],
                     ds.run(x, x_ch_off=x_ch_off)[0])
@@ -248,8 +239,7 @@ class TrunkPlan:
         self._encoders = encoders if self.n8 else None
         self._enc_all = encoders
         # block index (2, 4 or 6: a stride-2 block) from which the two trunks run as separate launch chains on two streams
-        sf_env = os.environ.get("W2C_SPLIT_TRUNKS")
-        self.split_from = (int(sf_env) if sf_env != "-1" else None) if sf_env not in (None, "") else 2
+        self.split_from = 2                  # layer2.0 (measured: forking at layer3.0 / layer4.0 or not at all is slower, profiles/r03_concurrency.txt)
         fbs = [e.feature_backbone.feature_backbone for e in encoders]
         # stem: [Cout][7][8][4] bf16, kx==7 / ci==3 zero
         ws, scs, shs = [], [], []
@@ -329,7 +319,7 @@ class TrunkPlan:
         # polyphase ring kernel takes 59 us for the pair (latency-bound: 2.8 TB/s on 168 MB).  Outputs = one compact slab per trunk.
         front = None
         c1f, _, dsf = self.blocks[split_from]
-        if _front_c64_ok(c1f, dsf, p) and not _NO_DUAL:
+        if _front_c64_ok(c1f, dsf, p):
             front = ops.conv_s2_front_c64(p, 0, c1f.wfrag_c64, c1f.scale, c1f.shift, dsf.wfrag_c64, dsf.scale, dsf.shift, c1f.groups, slabs=True)
         feat = self.squeezer.cout
         M, Hs, Ws, _ = p.shape
@@ -458,7 +448,7 @@ class TrunkPlan:
         # branch when the forward is captured into a HIP graph), so its half-size launches fill the CUs the fp8 half
         # leaves idle (320-640 workgroups per launch on 512 slots).
         L = ops.lanes(p.device)
-        side = bool(self.fp8["rest"]) and not _FP8_SERIAL
+        side = bool(self.fp8["rest"])
         if side:
             with L.on(1, after=(0,)):
                 self._rest_bf16(p, sq if squeezer_out is None else None, squeezer_out, feat)
@@ -537,7 +527,7 @@ class HeadPlan:
         self.b0 = torch.cat(b0s).contiguous().to(dev)
         self.n_feat = n_feat
         # fragment-ordered copy for the f32-MFMA form of fc.0 (ops.head_fc0_mfma; two heads of equal width; any row count: grid.z row blocks)
-        self.w0frag = ops.pack_fc0_frag(w0).to(dev) if (_HEAD_MFMA and w0.shape[0] % 32 == 0 and w0.shape[1] % 8 == 0) else None
+        self.w0frag = ops.pack_fc0_frag(w0).to(dev) if (w0.shape[0] % 32 == 0 and w0.shape[1] % 8 == 0) else None
 
     def run(self, qk_map, outs=None):
         """-> [key-head output, query-head output]; outs = preallocated (key, query) outputs for the two-head form."""
@@ -593,10 +583,9 @@ class DecoderPlan:
                 conv = torch.nn.Conv2d(feat, cout, 3, padding=1, bias=False).to(w.device)
                 with torch.no_grad():
                     conv.weight.copy_(w[:, i * feat:(i + 1) * feat])
-                part = ConvPlan([conv], relu=False)                 # (f32 output: w2c_conv3x3_wreg_f32out where the shape has a wreg form)
-                if os.environ.get("W2C_U_RING"):                    # A/B: the ring kernels' f32 epilogue (rounds 4-5)
-                    part.wfrag = None
-                self.cu_parts.append(part)
+                # f32 output: w2c_conv3x3_wreg_f32out where the shape has a weights-to-registers form (round 6: 1.0153 / 1.0111 / 1.0164 ->
+                # 1.0101 / 1.0074 / 1.0134 ms per forward against the ring kernels' f32 epilogue, tools/r06/ab.sh interleaved)
+                self.cu_parts.append(ConvPlan([conv], relu=False))
             self.cu = self.cu_parts[0]
             self.cu_bias = pred[0].bias.detach().float().contiguous()
             self.c_hidden = cout
@@ -699,7 +688,7 @@ class CommEngine:
         (Measured and rejected, profiles/r02_concurrency_experiments.txt: running the policy encoder's layer4 alone first so
         that the policy tail overlaps the value encoder's layer4 on a second stream -- 1.2988 vs 1.3024 ms, no gain: the
         tail's launches are inefficient, not idle, and a concurrent kernel only shares their CUs.)"""
-        if self.trunk.n8 or _NO_TAIL_OVERLAP:
+        if self.trunk.n8:
             sq = self.trunk.after_stem(s0)
             u = self.value_maps(sq)
             keys, querys = self.policy_tail(sq)
