@@ -2454,6 +2454,8 @@ static int wreg_form(int H, int W, int Cin, int Cout) {
     // layer1 (Cin = Cout = 64): the two-waves-per-SIMD register-resident kernel (conv_regh.inl), bit-identical to the ring kernels
     if (Cin == 64 && Cout == 64) return w2c_option(W2C_OPT_L1_FORM) == 54 ? 54 : 0;
     const int mincin = w2c_option(W2C_OPT_WREG_MINCIN);
+    // (layer2, Cin = 128, stays on the ring kernel: with K = 1152 the K-group reduction of this kernel family costs as much as the
+    //  K loop -- also in a persistent form that prefetches across tiles, profiles/r06_conv_experiments.txt section 3)
     if (mincin <= 0 || Cin < mincin) return 0;
     const int forced = w2c_option(W2C_OPT_WREG_FORM);
     if (forced == 80 && (Cout % 128) != 0) return 93;
