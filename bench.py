@@ -76,12 +76,13 @@ def build_cfg(arch, agent_num, size, query=True):
 
 
 def _n_graphs(model, x, fwd):
-    """number of single-branch graphs in the recorded program the timed steps replayed (0 if none)"""
+    """(single-branch graphs, host-issued regions) of the recorded program the timed steps replayed ((0, 0) if none)"""
     try:
         eng = model._engine_for(x, fwd._engine_cls)
-        return max([e[0].n_graphs for e in eng._graphs.values()] + [0])
+        progs = [e[0] for e in eng._graphs.values()]
+        return (max([p.n_graphs for p in progs] + [0]), max([p.n_calls for p in progs] + [0]))
     except Exception:                                        # noqa: BLE001
-        return 0
+        return (0, 0)
 
 
 def _free_port():
@@ -485,7 +486,7 @@ def main():
                   config=dict(workload=workload, preset=args.config, agents_total=N, agents_per_gpu=n_loc, global_batch=B,
                               frames_per_s=round(B * args.steps / elapsed, 2),
                               parallelism="agent-parallel x%d" % world, weights="deterministic filler (random-like)",
-                              launch=(("recorded program: %d single-branch hip-graphs on 2 lanes + event edges" % n_graphs
+                              launch=(("recorded program: %d single-branch hip-graphs on 2 lanes + %d host-issued regions (front, join) + event edges" % n_graphs
                                        if (world == 1 and not args.force_sharded) else "sharded: " + launch_form)
                                       if model.use_hip_graph else "eager")),
                   roofline=roofline, host_enqueue=host_enqueue,

@@ -309,25 +309,39 @@ class TrunkPlan:
         # workgroup rounds (layer4 / squeezers: 640 workgroups on 512 slots = 1.25 rounds, paid as 2); two independent chains have
         # no round boundary in common, so one chain's next launch fills the slots the other's tail leaves idle.  Same kernels,
         # same bits (results do not depend on the group count).
-        for c1, c2, ds in self.blocks[:split_from]:
-            t, idt = _block_front(c1, ds, p)
-            p = c2.run(t, residual=idt)
+        L = ops.lanes(p.device)                    # lane 0 (the caller's stream): the policy chain, lane 1: the value chain
         plans = self._single_trunk_plans(split_from)
         cin0 = self.blocks[split_from][0].cin
-        # layer2.0's front (conv1 3x3/s2 + the 1x1/s2 downsample, 64 -> 128) of BOTH trunks as one two-group launch of the persistent
-        # weights-stationary kernel (conv_s2regh.inl) before the fork: as two one-group launches at the head of the two chains the
-        # polyphase ring kernel takes 59 us for the pair (latency-bound: 2.8 TB/s on 168 MB).  Outputs = one compact slab per trunk.
-        front = None
         c1f, _, dsf = self.blocks[split_from]
-        if _front_c64_ok(c1f, dsf, p):
-            front = ops.conv_s2_front_c64(p, 0, c1f.wfrag_c64, c1f.scale, c1f.shift, dsf.wfrag_c64, dsf.scale, dsf.shift, c1f.groups, slabs=True)
+        p_in = p
+
+        def pre_fork():
+            """layer1 (both trunks, two-group launches) and layer2.0's front (conv1 3x3/s2 + the 1x1/s2 downsample, 64 -> 128) of BOTH
+            trunks as one two-group launch of the persistent weights-stationary kernel (conv_s2regh.inl) before the fork: as two
+            one-group launches at the head of the two chains the polyphase ring kernel takes 59 us for the pair (latency-bound: 2.8 TB/s
+            on 168 MB).  Front outputs = one compact slab per trunk."""
+            q = p_in
+            for c1, c2, ds in self.blocks[:split_from]:
+                t, idt = _block_front(c1, ds, q)
+                q = c2.run(t, residual=idt)
+            fr = None
+            if _front_c64_ok(c1f, dsf, q):
+                fr = ops.conv_s2_front_c64(q, 0, c1f.wfrag_c64, c1f.scale, c1f.shift, dsf.wfrag_c64, dsf.scale, dsf.shift, c1f.groups, slabs=True)
+            return q, fr
+
+        # Issued by the host at every replay of a recorded program, not captured (ops.Recorder.eager_static): a graph launch boundary on
+        # the critical path costs ~8-10 us on this runtime where an eager launch boundary costs ~2 -- with the front (stem, 4 layer1
+        # convs, this front: 6 launches) and the three launches behind the join kept out of the graphs the program replays as fast as
+        # the all-eager forward at a third of its host time (round 6, tools/r06/ab.sh, ms per forward, interleaved:
+        # all four segments as graphs 1.0136 / 1.0084 / 1.0085, join eager 1.0027 / 0.9979 / 1.0004; then on another box join eager
+        # 1.0678 / 1.0732 / 1.0680, front eager too 1.0602 / 1.0644 / 1.0612; all-eager forwards of the same jobs 1.000-1.011 / 1.058-1.067).
+        p, front = L.eager_static(pre_fork)
         feat = self.squeezer.cout
         M, Hs, Ws, _ = p.shape
         for _, _, ds in self.blocks[split_from:]:
             if ds is not None:
                 Hs, Ws = (Hs + 1) // 2, (Ws + 1) // 2
         sq = None if squeezer_out is not None else torch.empty((M, Hs, Ws, self.G * feat), dtype=BF16, device=p.device)
-        L = ops.lanes(p.device)                    # lane 0 (the caller's stream): the policy chain, lane 1: the value chain
         _stamp(0)
 
         # (Measured and not kept, profiles/r04_s2_front_c64.txt + DESIGN 10: starting the value chain behind block k of the policy chain,
@@ -757,11 +771,12 @@ class CommEngine:
             return finish(low), prob, action, nnz
         return self._forward_program(x, B, N, mode, labels, confusion)
 
-    # ---- the whole forward as ONE recorded program (ops.record_program): single-branch HIP graphs on this engine's two lanes -- front
-    # (stem -> layer1 -> layer2.0's front) | policy chain up to conv2 | conv3..5 + heads || value chain | decoder conv0 of the value maps
-    # | join -> graph + fusion -> decoder's last conv -> x32 upsample -- with event edges between them.  The stem reads the caller's
-    # tensor and the upsample writes the caller-owned output through device-resident pointer slots (include/w2c_hip.h "indirect
-    # operands"): per forward one tiny slot-setting launch + one replay of the program.
+    # ---- the whole forward as ONE recorded program (ops.record_program) on this engine's two lanes: front (stem -> layer1 -> layer2.0's
+    # front: six host-issued launches) -> fork -> the policy chain (layer2..4, squeezer, policy conv1..5, heads) as ONE single-branch HIP
+    # graph on the caller's stream || the value chain (layer2..4, squeezer, decoder conv0 of the value maps) as ONE single-branch graph
+    # on lane 1 -> join -> graph + fusion -> decoder's last conv -> x32 upsample (three host-issued launches), with two event edges.
+    # The stem reads the caller's tensor and the upsample writes the caller-owned output through device-resident pointer slots
+    # (include/w2c_hip.h "indirect operands"): per forward one slot-setting launch + one replay of the program.
     _SLOT_X, _SLOT_OUT, _SLOT_PACK, _SLOT_GT, _SLOT_HIST = 0, 1, 2, 3, 4
 
     def _out_like(self, x, N, labels, confusion):
@@ -801,19 +816,21 @@ class CommEngine:
         hists = None if hist is None else ops.SlotRef(slots, self._SLOT_HIST, hist)
 
         def whole():
-            s0 = self.trunk.stem(xs, N)
+            s0 = ops.lanes(dev).eager_static(lambda: self.trunk.stem(xs, N))      # (host-issued, see TrunkPlan.after_stem)
             _, u, keys, querys = self.encode_from_stem(s0)
             pack2 = ops.SlotRef(slots, self._SLOT_PACK, ops.graph_outputs(dev, B, N, N)[0])
-            low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode, pack2=pack2)
-            pack = self._last_pack
-            if confusion is not None:
-                ops.upsample32_argmax_confusion(low, self.n_classes, gts, hists, want_labels=labels, out=outs,
-                                                ws=self._confusion_ws(low.device))
-            elif labels:
-                ops.upsample32_argmax(low, self.n_classes, out=outs)
-            else:
-                ops.upsample_bilinear32(low, self.n_classes, out=outs)
-            return pack
+
+            def join():
+                low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode, pack2=pack2)
+                if confusion is not None:
+                    ops.upsample32_argmax_confusion(low, self.n_classes, gts, hists, want_labels=labels, out=outs,
+                                                    ws=self._confusion_ws(low.device))
+                elif labels:
+                    ops.upsample32_argmax(low, self.n_classes, out=outs)
+                else:
+                    ops.upsample_bilinear32(low, self.n_classes, out=outs)
+            ops.lanes(dev).eager(join)              # the three launches behind the join: host-issued at every replay (TrunkPlan.after_stem)
+            return self._last_pack
 
         scratch = []                                # what the warm-up forwards write through the slots: alive until they have run
 

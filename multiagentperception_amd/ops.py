@@ -45,6 +45,36 @@ def _p(t):
 _tls = threading.local()          # per-thread (DataParallel runs one thread per replica): the opt-in conv timer, the lanes recorder
 
 
+class _Arena:
+    """Outputs of an eagerly replayed region of a recorded program (Recorder.eager_static): the region's kernels are issued by the host at
+    every replay, but what they write is read by CAPTURED graphs, so their output tensors must keep their addresses -- the first run
+    allocates them (mode "record"), every later run hands the same tensors out again in allocation order (mode "replay")."""
+
+    def __init__(self):
+        self.tensors, self.mode, self.i = [], "record", 0
+
+    def take(self, shape, dtype, device):
+        if self.mode == "record":
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.tensors.append(t)
+            return t
+        if self.i >= len(self.tensors):
+            raise W2CError("eager region of a recorded program allocates more outputs at replay than when it was recorded")
+        t = self.tensors[self.i]
+        self.i += 1
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            raise W2CError("eager region of a recorded program: output %d changed shape / dtype between recording and replay" % (self.i - 1))
+        return t
+
+
+def _empty(shape, dtype, device):
+    """torch.empty for a wrapper's OUTPUT tensor (through the active arena, if a recorded program is replaying an eager region)"""
+    ar = getattr(_tls, "arena", None)
+    if ar is not None:
+        return ar.take(tuple(shape), dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
 class SlotRef:
     """Stand-in for a caller-owned tensor whose ADDRESS a kernel reads from a device-resident pointer slot when it starts
     (include/w2c_hip.h "indirect operands": the argument is the slot's address with bit 0 set).  Carries the shape / dtype / device the
@@ -124,6 +154,8 @@ class capture:
 #     L.wait(tok)                        the current lane goes on only behind that point
 #     L.join(1)                          the current lane goes on only behind everything lane 1 has been given
 #     L.eager(fn)                        something that must be issued by the host every time (an RCCL collective): never captured
+#     L.eager_static(fn)                 a few launches kept out of the graphs (issued by the host at every replay) whose OUTPUTS captured
+#                                        graphs read: they keep their addresses (ops._Arena)
 # Lane 0 is the caller's stream, lanes 1.. are long-lived side streams.  Two executors implement the same five verbs:
 #   * EagerLanes  -- stream / event calls, the launches go out as the Python code runs (model.use_hip_graph = False);
 #   * a recorder  -- record_program(): the SAME Python code is run once under capture and cut, at exactly those verbs, into a list of
@@ -188,6 +220,9 @@ class EagerLanes:
             cur.wait_stream(s)
 
     def eager(self, fn):
+        return fn()
+
+    def eager_static(self, fn):
         return fn()
 
 
@@ -294,6 +329,34 @@ class _Recorder:
         self._open(lane)
         return res
 
+    def eager_static(self, fn):
+        """fn's launches are issued by the host at every replay (no graph, hence no graph-launch boundary in front of and behind them:
+        ~8-10 us each on this runtime, see the measurements in engine.CommEngine._record), but its outputs feed captured graphs: they
+        come from an arena that hands the SAME tensors out at every replay.  Returns fn's result (those tensors)."""
+        lane = self._lane
+        self._close()
+        arena = _Arena()
+        box = {}
+
+        def run():
+            prev = getattr(_tls, "arena", None)
+            _tls.arena = arena
+            arena.i = 0
+            try:
+                box["res"] = fn()
+            finally:
+                _tls.arena = prev
+            if arena.mode == "replay" and arena.i != len(arena.tensors):
+                raise W2CError("eager region of a recorded program allocated fewer outputs at replay than when it was recorded")
+
+        with torch.cuda.stream(self.cap[lane]):
+            run()
+        arena.mode = "replay"
+        res = box["res"]
+        self.prog.append(("call", lane, run))
+        self._open(lane)
+        return res
+
 
 def lanes(dev):
     """the lanes executor in effect on this thread: the recorder inside record_program(), else stream / event calls"""
@@ -315,6 +378,7 @@ class Program:
         n_side = max([st[1] for st in prog] + [st[2] for st in prog if st[0] == "sync"] + [0])
         self.side = [_new_side_stream(dev) for _ in range(n_side)]
         self.n_graphs = sum(1 for st in prog if st[0] == "graph")
+        self.n_calls = sum(1 for st in prog if st[0] == "call")
 
     def replay(self):
         s0 = torch.cuda.current_stream(self.dev)
@@ -510,7 +574,7 @@ def stem_conv7x7_bn_relu(x, n_agents, w_packed, scale, shift, out=None):
         raise W2CError("stem: expected f32 [B, 3*%d, H, W], got %s %s" % (n_agents, tuple(x.shape), x.dtype))
     cout = scale.numel()
     if out is None:
-        out = torch.empty((n_agents * B, H // 2, W // 2, cout), dtype=BF16, device=dev)
+        out = _empty((n_agents * B, H // 2, W // 2, cout), dtype=BF16, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_stem_conv7x7_bn_relu(_p(x), B, n_agents, H, W, _p(w_packed), _p(scale), _p(shift),
                                                      cout, _p(out), _stream(dev)), "w2c_stem_conv7x7_bn_relu")
@@ -525,7 +589,7 @@ def stem_conv7x7_bn_relu_maxpool(x, n_agents, w_packed, scale, shift, out=None):
         raise W2CError("stem: expected f32 [B, 3*%d, H, W], got %s %s" % (n_agents, tuple(x.shape), x.dtype))
     cout = scale.numel()
     if out is None:
-        out = torch.empty((n_agents * B, H // 4, W // 4, cout), dtype=BF16, device=dev)
+        out = _empty((n_agents * B, H // 4, W // 4, cout), dtype=BF16, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_stem_conv7x7_bn_relu_maxpool(_p(x), B, n_agents, H, W, _p(w_packed), _p(scale),
                                                              _p(shift), cout, _p(out), _stream(dev)),
@@ -544,7 +608,7 @@ def stem_u8_conv7x7_bn_relu_maxpool(frames, w_packed, scale, shift, mean_bgr=FRA
     B, N, H, W, _ = frames.shape
     cout = scale.numel()
     if out is None:
-        out = torch.empty((N * B, H // 4, W // 4, cout), dtype=BF16, device=dev)
+        out = _empty((N * B, H // 4, W // 4, cout), dtype=BF16, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_stem_u8_conv7x7_bn_relu_maxpool(_p(frames), float(mean_bgr[0]), float(mean_bgr[1]),
                                                                 float(mean_bgr[2]), B, N, H, W, _p(w_packed), _p(scale),
@@ -557,7 +621,7 @@ def maxpool3x3s2(x, out=None):
     dev = _need_gpu(x, out)
     M, H, W, C = x.shape
     if out is None:
-        out = torch.empty((M, H // 2, W // 2, C), dtype=BF16, device=dev)
+        out = _empty((M, H // 2, W // 2, C), dtype=BF16, device=dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_maxpool3x3s2(_p(x), M, H, W, C, _p(out), _stream(dev)), "w2c_maxpool3x3s2")
     return out
@@ -646,7 +710,7 @@ def conv_igemm(x, x_ch_off, cin, w_packed, cout, ksize, stride, groups, scale, s
     if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
         raise W2CError("conv: channels [%d, %d) outside the tensor's %d channels" % (x_ch_off, x_ch_off + groups * cin, xcs))
     if out is None:
-        out = torch.empty((M, Ho, Wo, out_cstride), dtype=torch.float32 if out_f32 else BF16, device=dev)
+        out = _empty((M, Ho, Wo, out_cstride), dtype=torch.float32 if out_f32 else BF16, device=dev)
     if tuple(out.shape) != (M, Ho, Wo, out_cstride):
         raise W2CError("conv: bad out shape %s, want %s" % (tuple(out.shape), (M, Ho, Wo, out_cstride)))
     if residual is not None and tuple(residual.shape) != tuple(out.shape):
@@ -720,7 +784,7 @@ def conv3x3_wreg_f32(x, x_ch_off, cin, wfrag, cout, scale, shift, relu=False, ou
     dev = _need_gpu(x, wfrag, scale, shift, out)
     M, H, W, xcs = x.shape
     if out is None:
-        out = torch.empty((M, H, W, cout), dtype=torch.float32, device=dev)
+        out = _empty((M, H, W, cout), dtype=torch.float32, device=dev)
     ocs = out.shape[3]
     if tuple(out.shape[:3]) != (M, H, W) or out.dtype != torch.float32 or out_ch_off % 4 or out_ch_off + cout > ocs:
         raise W2CError("conv3x3_wreg_f32: out must be f32 [M,H,W,>= out_ch_off + cout]")
@@ -773,7 +837,7 @@ def conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, residual=N
     if out_cstride is None:
         out_cstride = out.shape[3] if out is not None else groups * cout
     if out is None:
-        out = torch.empty((M, H, W, out_cstride), dtype=BF16, device=dev)
+        out = _empty((M, H, W, out_cstride), dtype=BF16, device=dev)
     if tuple(out.shape) != (M, H, W, out_cstride) or out.dtype != BF16:
         raise W2CError("conv3x3_wreg: bad out tensor")
     if residual is not None and (tuple(residual.shape) != tuple(out.shape) or out_ch_off):
@@ -884,11 +948,11 @@ def conv_s2_block(x, x_ch_off, cin, w3, scale3, shift3, w1, scale1, shift1, cout
     if x_ch_off < 0 or x_ch_off + groups * cin > xcs:
         raise W2CError("conv_s2_block: channels outside the tensor")
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-    t16 = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev) if t_bf16 else None
-    t8 = torch.empty((M, Ho, Wo, groups * cout), dtype=torch.uint8, device=dev) if t_fp8_scale is not None else None
+    t16 = _empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev) if t_bf16 else None
+    t8 = _empty((M, Ho, Wo, groups * cout), dtype=torch.uint8, device=dev) if t_fp8_scale is not None else None
     if t16 is None and t8 is None:
         raise W2CError("conv_s2_block: no conv1 output requested")
-    idt = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    idt = _empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
     es = 1 if f8 else 2
     timer = getattr(_tls, "conv_timer", None)
     tok = timer.begin(dev) if timer is not None else None
@@ -932,8 +996,8 @@ def conv_s2_block_wreg(x, x_ch_off, cin, w3frag, scale3, shift3, w1frag, scale1,
     if tuple(w3frag.shape) != (groups, cout, 9 * cin) or tuple(w1frag.shape) != (groups, cout, cin):
         raise W2CError("conv_s2_block_wreg: weight shapes")
     Ho, Wo = H // 2, W // 2
-    t16 = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
-    idt = torch.empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    t16 = _empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
+    idt = _empty((M, Ho, Wo, groups * cout), dtype=BF16, device=dev)
     timer = getattr(_tls, "conv_timer", None)
     tok = timer.begin(dev) if timer is not None else None
     with torch.cuda.device(dev):
@@ -969,8 +1033,8 @@ def conv_s2_front_c64(x, x_ch_off, w3frag, scale3, shift3, w1frag, scale1, shift
         shape, cs, gs = (groups, M, Ho, Wo, 128), 128, M * Ho * Wo * 128
     else:
         shape, cs, gs = (M, Ho, Wo, groups * 128), groups * 128, 128
-    t16 = torch.empty(shape, dtype=BF16, device=dev)
-    idt = torch.empty(shape, dtype=BF16, device=dev)
+    t16 = _empty(shape, dtype=BF16, device=dev)
+    idt = _empty(shape, dtype=BF16, device=dev)
     timer = getattr(_tls, "conv_timer", None)
     tok = timer.begin(dev) if timer is not None else None
     with torch.cuda.device(dev):
@@ -983,6 +1047,9 @@ def conv_s2_front_c64(x, x_ch_off, w3frag, scale3, shift3, w1frag, scale1, shift
         nbytes = M * H * W * 64 * groups * 2 + M * Ho * Wo * 128 * groups * 4 + groups * 128 * 10 * 64 * 2
         timer.end(tok, dev, flops, (M * Ho * Wo, 64, 128, "3+1", 2, groups), nbytes)
     return t16, idt
+
+
+_wgrad_ws = {}
 
 
 def stem_conv7x7_train(x_nhwc3, w_packed, out=None):

@@ -267,7 +267,7 @@ class AgentParallelForward:
         def step(xs, outs, packs):
             L = ops.lanes(dev)
             works = []
-            eng.trunk.stem(xs, n_loc, out=st.s0)
+            L.eager(lambda: eng.trunk.stem(xs, n_loc, out=st.s0))      # host-issued at every replay (engine.TrunkPlan.after_stem says why)
 
             def value_tail(v):
                 # (lane 1) U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K
@@ -289,11 +289,12 @@ class AgentParallelForward:
             def wait_all():
                 while works:
                     exchange_wait(works.pop(0))
-            L.eager(wait_all)
-            low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=packs, u_own=st.u_own)
-            pack = eng._last_pack
-            ops.upsample_bilinear32(low, eng.n_classes, out=outs)
-            return pack
+            def join():
+                wait_all()
+                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=packs, u_own=st.u_own)
+                ops.upsample_bilinear32(low, eng.n_classes, out=outs)
+            L.eager(join)
+            return eng._last_pack
 
         dense = (self.world - 1) * n_loc * B
         self.last_exchange = (dense, dense)
@@ -317,7 +318,7 @@ class AgentParallelForward:
         packc = torch.empty_like(program.result)
         ops.set_slots(slots, [x, out, packc])
         program.replay()
-        self.launch_form = "one program: %d single-branch hip-graphs + eager RCCL all-gathers" % program.n_graphs
+        self.launch_form = "one program: %d single-branch hip-graphs + %d host-issued steps incl. the RCCL all-gathers" % (program.n_graphs, program.n_calls)
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
         return out, prob, action, nnz
 
