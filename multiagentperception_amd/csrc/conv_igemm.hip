@@ -114,7 +114,13 @@ struct ConvArgs {
     int y2cs;
     long long y2gs;            // conv_s2regh.inl: element offset between the groups' slabs of y2 (ygs is that of y)
     int xcd2d;                 // patch kernel, 2 groups on a flattened grid: XCD -> (group, half of the tiles, half of the channel tiles)
+    // conv_wreg.inl: ceil(2^32 / d) for the tile decode's four divisors (ntn, ntn / 4, tiles_x, tiles_x * tiles_y): q = umulhi(n, magic) is
+    // exact while n * d < 2^32 -- a scalar multiply instead of the ~40-instruction reciprocal sequence of a run-time division, four times
+    // in front of a workgroup's first memory request
+    unsigned mg_ntn, mg_qn, mg_tx, mg_txy;
 };
+static inline unsigned w2c_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+__device__ __forceinline__ int w2c_fastdiv(int n, int d, unsigned magic) { return d <= 1 ? n : (int)__umulhi((unsigned)n, magic); }
 
 // element size / channels per K-step of the two operand types: a K-step is always ONE 128-byte run per row
 template <bool F8> struct OpT { static constexpr int ES = F8 ? 1 : 2; static constexpr int CK = F8 ? 128 : 64; };

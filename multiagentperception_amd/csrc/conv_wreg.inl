@@ -66,15 +66,17 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
         // time-neutral (the Infinity Cache holds everything).  Placement only: the result does not depend on it.
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         const int qn = p.ntn >> 2, hm = p.ntm >> 1;
-        const int tm_l = loc / qn;
+        const int tm_l = w2c_fastdiv(loc, qn, p.mg_qn);
         tn = (xcd >> 1) * qn + (loc - tm_l * qn);
         tsp = (xcd & 1) * hm + tm_l;
     } else {
         const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
-        tsp = tile / p.ntn;
+        tsp = w2c_fastdiv(tile, p.ntn, p.mg_ntn);
         tn = tile - tsp * p.ntn;
     }
-    const int txi = tsp % tiles_x, tyi = (tsp / tiles_x) % tiles_y, img = tsp / (tiles_x * tiles_y);
+    const int img = w2c_fastdiv(tsp, tiles_x * tiles_y, p.mg_txy);
+    const int trem = tsp - img * (tiles_x * tiles_y);
+    const int tyi = w2c_fastdiv(trem, tiles_x, p.mg_tx), txi = trem - tyi * tiles_x;
     const int y0 = tyi * 8, x0 = txi * 16;
     const int n0 = tn * (NN * CW) + nw * CW;        // this wave's first output channel inside the group
     const int nchunks = p.Cin >> 6, KT = nchunks * 9;
@@ -131,13 +133,18 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
         }
     };
 
+    // KS == 4 (one slice per tap): the first tap of the first chunk takes the constant 0 as its C operand instead of 128 accumulator
+    // writes in front of the loop (v_accvgpr_write is a VALU instruction: 0.25 us of a SIMD that also hosts another workgroup's MFMAs)
+    constexpr bool ZERO_C = (KK == 1);
     f32x16_t acc[4][NB];
+    if constexpr (!ZERO_C) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
 
     // Pixel-block order of this wave's accumulators: acc[i] is pixel block blk(i) of the tile (rows 2 blk, 2 blk + 1).  The order is
     // chosen per K group so that the reduction after the loop is the SAME code in every wave (no accumulator flows through a
@@ -174,12 +181,18 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const bf16x8_t*>(r + blkoff[i]);
     };
-    auto mfma8 = [&](const u32x4_t (&A)[NB][KK], const bf16x8_t (&fb)[4], int q) {
+    auto mfma8 = [&](const u32x4_t (&A)[NB][KK], const bf16x8_t (&fb)[4], int q, auto firstc) {
+        constexpr bool FIRST = decltype(firstc)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[j][q]), fb[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) {
+                if constexpr (FIRST)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[j][q]), fb[i],
+                                                                        f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[j][q]), fb[i], acc[i][j], 0, 0, 0);
+            }
     };
 
     // ---- main loop.  VMEM queue of a wave, in issue order:  P(0) P(1) A(0) A(1) | A(2) .. A(9) [sync 0] P(2) A(10) | ...
@@ -197,8 +210,9 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
     if constexpr (ABL & 2) read_b(fb[1], smem, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
     // one chunk = 9 taps, fully unrolled; PAR = parity of the chunk's first slice in the fb[] double buffer
-    auto chunk_body = [&](auto parc, int cc, int bcur, int bnext) {
+    auto chunk_body = [&](auto parc, int cc, int bcur, int bnext, auto firstcc) {
         constexpr int PAR = decltype(parc)::value;
+        constexpr bool FIRSTC = decltype(firstcc)::value;           // the tile's first chunk (ZERO_C forms only)
         const char* pcur = smem + bcur * PATCH_STRIDE;
         const char* pnext = smem + bnext * PATCH_STRIDE;
         const int t0 = cc * 9;
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
                     else if constexpr (tap < 8) read_b(nxt, pcur, std::integral_constant<int, (tap + 1) % 9>{}, std::integral_constant<int, 0>{});
                     else read_b(nxt, pnext, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
                 }
-                mfma8(AR[tap % R], cur, q);
+                mfma8(AR[tap % R], cur, q, std::integral_constant<bool, FIRSTC && tap == 0 && q == 0>{});
                 if constexpr (!(ABL & 2)) {
 #pragma unroll
                     for (int z = 0; z < 4; ++z) {
@@ -249,15 +263,18 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
     {
         int bcur = 0, bnext = 1;
         auto adv = [&]() { bcur = bnext; bnext = bnext + 1 == 3 ? 0 : bnext + 1; };
+        using No_ = std::integral_constant<bool, false>;
         if constexpr ((9 * KK) % 2 == 0) {
-            for (int cc = 0; cc < nchunks; ++cc) { chunk_body(std::integral_constant<int, 0>{}, cc, bcur, bnext); adv(); }
+            for (int cc = 0; cc < nchunks; ++cc) { chunk_body(std::integral_constant<int, 0>{}, cc, bcur, bnext, No_{}); adv(); }
         } else {
-            int cc = 0;
+            // (odd slice count per chunk: the fragment double buffer's parity alternates from chunk to chunk)
+            chunk_body(std::integral_constant<int, 0>{}, 0, bcur, bnext, std::integral_constant<bool, ZERO_C>{}); adv();
+            int cc = 1;
             for (; cc + 1 < nchunks; cc += 2) {
-                chunk_body(std::integral_constant<int, 0>{}, cc, bcur, bnext); adv();
-                chunk_body(std::integral_constant<int, 1>{}, cc + 1, bcur, bnext); adv();
+                chunk_body(std::integral_constant<int, 1>{}, cc, bcur, bnext, No_{}); adv();
+                chunk_body(std::integral_constant<int, 0>{}, cc + 1, bcur, bnext, No_{}); adv();
             }
-            if (cc < nchunks) chunk_body(std::integral_constant<int, 0>{}, cc, bcur, bnext);
+            if (cc < nchunks) chunk_body(std::integral_constant<int, 1>{}, cc, bcur, bnext, No_{});
         }
     }
     // ---- epilogue operands, issued before the exchange so that their latency hides under it: this wave will own pixel blocks
@@ -381,6 +398,11 @@ int launch_wreg(ConvArgs& a, int groups, hipStream_t s) {
         return W2C_E_ARG;
     a.ntm = a.M * (a.H / 8) * (a.W / 16);
     a.ntn = a.Cout / (NN * 32 * NB);
+    if ((long)a.ntm * a.ntn * ((a.H / 8) * (a.W / 16) > a.ntn ? (a.H / 8) * (a.W / 16) : a.ntn) >= (1ll << 32)) return W2C_E_ARG;   // (fast-division range)
+    a.mg_ntn = w2c_magic((unsigned)a.ntn);
+    a.mg_qn = w2c_magic((unsigned)(a.ntn >> 2));
+    a.mg_tx = w2c_magic((unsigned)(a.W / 16));
+    a.mg_txy = w2c_magic((unsigned)((a.H / 8) * (a.W / 16)));
     constexpr int patch = 3 * ((23 + NN * KS - 1) / (NN * KS)) * NN * KS * 1024;
     constexpr int xchg = KS > 1 ? NN * KS * 8192 * NB : 0;
     constexpr int lds = (patch > xchg ? patch : xchg) + NN * KS * 512;
