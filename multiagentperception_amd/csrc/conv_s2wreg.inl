@@ -58,8 +58,10 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3s2_wreg_kernel(ConvArg
     const int tiles_x = p.Wo >> 4, tiles_y = p.Ho >> 3;
     const int g = blockIdx.y;
     const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
-    const int tsp = tile / p.ntn, tn = tile - tsp * p.ntn;
-    const int txi = tsp % tiles_x, tyi = (tsp / tiles_x) % tiles_y, img = tsp / (tiles_x * tiles_y);
+    const int tsp = w2c_fastdiv(tile, p.ntn, p.mg_ntn), tn = tile - tsp * p.ntn;          // (magic-number divisions: conv_wreg.inl)
+    const int img = w2c_fastdiv(tsp, tiles_x * tiles_y, p.mg_txy);
+    const int trem = tsp - img * (tiles_x * tiles_y);
+    const int tyi = w2c_fastdiv(trem, tiles_x, p.mg_tx), txi = trem - tyi * tiles_x;
     const int oy0 = tyi * 8, ox0 = txi * 16;
     const int n0 = tn * (NN * 64) + nw * 64;
     const int nchunks = p.Cin >> 6, KT = nchunks * 9;
@@ -69,15 +71,29 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3s2_wreg_kernel(ConvArg
     const bool dual = p.w2 != nullptr;
     float* const ssb = reinterpret_cast<float*>(smem + SS_BASE + nw * 1024);
     float* const ssw = ssb + lhi * 4;
-    ssb[lane] = p.scale[g * p.Cout + n0 + lane];
-    ssb[64 + lane] = p.shift[g * p.Cout + n0 + lane];
-    if (dual) {
-        ssb[128 + lane] = p.scale2[g * p.Cout + n0 + lane];
-        ssb[192 + lane] = p.shift2[g * p.Cout + n0 + lane];
+    const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)W2C_LPTR(smem));
+    {
+        // as dword LDS-DMA requests, the OLDEST vector-memory operations of the wave (every hand-counted wait below covers them): a
+        // load + ds_write here put the load's round trip in front of the workgroup's first patch request (conv_wreg.inl, round 6)
+        const unsigned voff = (unsigned)(g * p.Cout + n0 + lane) * 4u;
+        auto park = [&](const float* src, unsigned dst) {
+            const unsigned long long a = reinterpret_cast<unsigned long long>(src);
+            const u32x4_t srd = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)),
+                                 0x7FFFFFFFu, 0x00020000u};
+            unsigned keep;
+            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(voff), "s"(srd) : "memory");
+        };
+        const unsigned d0 = lds_base + SS_BASE + (unsigned)nw * 1024u;
+        park(p.scale, d0);
+        park(p.shift, d0 + 256u);
+        if (dual) {
+            park(p.scale2, d0 + 512u);
+            park(p.shift2, d0 + 768u);
+        }
     }
 
     // ---- phase patches: LDS-DMA from inline asm, counted by hand ----
-    const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)W2C_LPTR(smem));
     const unsigned long long xaddr = reinterpret_cast<unsigned long long>(p.x) + (unsigned long long)g * p.Cin * 2;
     const unsigned x_bytes = (unsigned)((size_t)p.M * p.H * p.W * p.xcs * 2);
     const u32x4_t srd_x = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xaddr),
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3s2_wreg_kernel(ConvArg
         const int chunk = (lane & 7) ^ ((b_c >> 1) & 7);            // swizzle keyed on the patch column, as in conv_wreg.inl
         const int by = oy0 - 1 + b_r, bx = ox0 - 1 + b_c;
         const bool ok = (by >= 0) & (bx >= 0) & (b_c <= 16);
-        return ok ? (unsigned)((((long)img * p.H + 2 * by) * p.W + 2 * bx) * p.xcs * 2 + chunk * 16) : 0x80000000u;
+        return ok ? (unsigned)(((img * p.H + 2 * by) * p.W + 2 * bx) * p.xcs * 2 + chunk * 16) : 0x80000000u;   // (< 2 GiB: the launcher)
     };
     auto piece_of = [&](int j) { const int pc = wave + NW * j; return pc < NPIECE ? pc : NPIECE - 1; };
     unsigned pa_off[P_INSTR];
@@ -418,6 +434,11 @@ int launch_s2wreg(ConvArgs& a, int groups, hipStream_t s) {
         return W2C_E_ARG;
     a.ntm = a.M * (a.Ho / 8) * (a.Wo / 16);
     a.ntn = a.Cout / (NN * 64);
+    if ((long)a.ntm * a.ntn * ((a.Ho / 8) * (a.Wo / 16) > a.ntn ? (a.Ho / 8) * (a.Wo / 16) : a.ntn) >= (1ll << 32)) return W2C_E_ARG;   // (fast-division range)
+    a.mg_ntn = w2c_magic((unsigned)a.ntn);
+    a.mg_qn = 0;
+    a.mg_tx = w2c_magic((unsigned)(a.Wo / 16));
+    a.mg_txy = w2c_magic((unsigned)((a.Ho / 8) * (a.Wo / 16)));
     constexpr int patch = 34 * 2304;
     constexpr int xchg = NN * KS * 16384;
     constexpr int lds = (patch > xchg ? patch : xchg) + NN * 1024;

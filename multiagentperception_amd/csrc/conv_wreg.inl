@@ -85,10 +85,8 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
     constexpr int XR = 8192 * NB;                  // exchange region of a wave (round 1: two pixel blocks x NB accumulators x 4 KB)
     constexpr int SS_BASE = (3 * PATCH_STRIDE > NW * XR ? 3 * PATCH_STRIDE : NW * XR);
     float* const ssw = reinterpret_cast<float*>(smem + SS_BASE + wave * 512) + lhi * 4;
-    if (NB == 2 || lane < CW) {
-        reinterpret_cast<float*>(smem + SS_BASE + wave * 512)[lane] = p.scale[g * p.Cout + n0 + lane];
-        reinterpret_cast<float*>(smem + SS_BASE + wave * 512)[64 + lane] = p.shift[g * p.Cout + n0 + lane];
-    }
+    // (parked by two dword LDS-DMA requests behind the first patches, below: a load + ds_write here put the load's whole round trip in
+    //  front of the workgroup's first patch request)
 
     // ---- input patch: LDS-DMA from inline asm (hidden from the compiler's vmcnt bookkeeping: counted by hand below) ----
     const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)W2C_LPTR(smem));
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
         const int chunk = (lane & 7) ^ ((px >> 1) & 7);             // swizzle keyed on the patch column (see the ring kernel)
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = (q < NP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        pa_off[j] = ok ? (unsigned)((((long)img * p.H + iy) * p.W + ix) * p.xcs * 2 + chunk * 16) : 0x80000000u;
+        pa_off[j] = ok ? (unsigned)(((img * p.H + iy) * p.W + ix) * p.xcs * 2 + chunk * 16) : 0x80000000u;   // (< 2 GiB: launch_wreg)
     }
     auto issue_patch = [&](int cc, int buf) {
         const unsigned soff = (unsigned)cc * 128u;
@@ -201,6 +199,21 @@ __global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_ke
     bf16x8_t fb[2][4];
     issue_patch(0, 0);
     if (nchunks > 1) issue_patch(1, 1);
+    {
+        // BN scale | shift of this wave's channels -> LDS, one dword per lane each, as LDS-DMA (counted like the patch pieces: they are
+        // older than every weight load, so each hand-counted wait below covers them)
+        const unsigned long long sca = reinterpret_cast<unsigned long long>(p.scale), sha = reinterpret_cast<unsigned long long>(p.shift);
+        const u32x4_t srd_sc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sca), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sca >> 32)),
+                                0x7FFFFFFFu, 0x00020000u};
+        const u32x4_t srd_sh = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sha), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sha >> 32)),
+                                0x7FFFFFFFu, 0x00020000u};
+        const unsigned voff = (NB == 2 || lane < CW) ? (unsigned)(g * p.Cout + n0 + lane) * 4u : 0x80000000u;
+        const unsigned dst = lds_base + SS_BASE + (unsigned)wave * 512u;
+        unsigned keep;
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\t"
+                     "s_add_u32 m0, m0, 256\n\ts_nop 0\n\tbuffer_load_dword %2, %4, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(voff), "s"(srd_sc), "s"(srd_sh) : "memory");
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) load_a(AR[d], d);
     if (nchunks > 1) wait_vmcnt<P_INSTR + NB * KK * D>(); else wait_vmcnt<NB * KK * D>();
