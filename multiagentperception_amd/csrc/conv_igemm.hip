@@ -118,6 +118,7 @@ struct ConvArgs {
     // exact while n * d < 2^32 -- a scalar multiply instead of the ~40-instruction reciprocal sequence of a run-time division, four times
     // in front of a workgroup's first memory request
     unsigned mg_ntn, mg_qn, mg_tx, mg_txy;
+    unsigned mg_hw, mg_wo;     // the same for the implicit-GEMM kernels' row -> (image, oy, ox) decode (divisors Ho * Wo, Wo): set by fill_args
 };
 static inline unsigned w2c_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 __device__ __forceinline__ int w2c_fastdiv(int n, int d, unsigned magic) { return d <= 1 ? n : (int)__umulhi((unsigned)n, magic); }
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs p) {
         const int chunk = lpos ^ swz(r);
         if (gr < p.rows) {
             const int hw = p.Ho * p.Wo;
-            const int m = gr / hw;
+            const int m = w2c_fastdiv(gr, hw, p.mg_hw);              // (rows < 2^29, hw <= rows: exact; round 6)
             const int rem = gr - m * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int oy = w2c_fastdiv(rem, p.Wo, p.mg_wo), ox = rem - oy * p.Wo;
             a_iy0[j] = oy * p.stride - p.pad;
             a_ix0[j] = ox * p.stride - p.pad;
             a_base[j] = (int)(((long)m * p.H * p.W + (long)a_iy0[j] * p.W + a_ix0[j]) * p.xcs * ES + chunk * 16);
@@ -635,18 +636,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         const int hn = p.ntn >> 1, hm = p.ntm >> 1;
         g = xcd >> 2;
-        const int tm_l = loc / hn;
+        const int tm_l = w2c_fastdiv(loc, hn, p.mg_qn);               // (magic-number divisions, round 6: see ConvArgs)
         tn = (xcd & 1) * hn + (loc - tm_l * hn);
         tsp = ((xcd >> 1) & 1) * hm + tm_l;
     } else {
         g = blockIdx.y;
         const int tile = xcd_remap(blockIdx.x, p.ntm * p.ntn);
-        tsp = tile / p.ntn;
+        tsp = w2c_fastdiv(tile, p.ntn, p.mg_ntn);
         tn = tile - tsp * p.ntn;
     }
-    const int txi = tsp % tiles_x;
-    const int tyi = (tsp / tiles_x) % tiles_y;
-    const int img = tsp / (tiles_x * tiles_y);
+    const int img = w2c_fastdiv(tsp, tiles_x * tiles_y, p.mg_txy);
+    const int trem = tsp - img * (tiles_x * tiles_y);
+    const int tyi = w2c_fastdiv(trem, tiles_x, p.mg_tx);
+    const int txi = trem - tyi * tiles_x;
     const int y0 = tyi * TH, x0 = txi * TW, n0 = tn * BN;
 
     const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)g * p.Cin * ES;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(ConvArgs p)
         const int chunk = lpos ^ ((px >> 1) & 7);                    // swizzle keyed on the patch COLUMN (see load_frags)
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        pa_off[j] = ok ? (unsigned)((((long)img * p.H + iy) * p.W + ix) * p.xcs * ES + chunk * 16) : 0x80000000u;
+        pa_off[j] = ok ? (unsigned)(((img * p.H + iy) * p.W + ix) * p.xcs * ES + chunk * 16) : 0x80000000u;   // (< 2 GiB: fill_args)
     }
     auto issue_patch = [&](int cc, int buf) {
         char* dst = patch0 + buf * PATCH_BYTES;
@@ -1908,6 +1910,11 @@ int launch_patch(ConvArgs& a, int groups, hipStream_t s) {
     if (PB == 1 && a.Cin != CK) return W2C_E_ARG;
     a.ntm = a.M * (a.H / TH) * (a.W / TW);
     a.ntn = a.Cout / BN;
+    if ((long)a.ntm * a.ntn * ((a.H / TH) * (a.W / TW) > a.ntn ? (a.H / TH) * (a.W / TW) : a.ntn) >= (1ll << 32)) return W2C_E_ARG;   // (fast-division range)
+    a.mg_ntn = w2c_magic((unsigned)a.ntn);
+    a.mg_qn = w2c_magic((unsigned)(a.ntn >> 1));
+    a.mg_tx = w2c_magic((unsigned)(a.W / TW));
+    a.mg_txy = w2c_magic((unsigned)((a.H / TH) * (a.W / TW)));
     constexpr int ring = PB * (TH + 2) * (TW + 2) * 128 + STAGES * BN * 128;
     constexpr int epi = TH * TW * (BN + 4) * 4;
     constexpr int lds = ring > epi ? ring : epi;
@@ -2038,9 +2045,9 @@ __global__ __launch_bounds__(MAXT) void conv_inwg_splitk_kernel(ConvArgs p) {
         const int gr = m0 + i * 32 + l31;
         if (gr < p.rows) {
             const int hw = p.Ho * p.Wo;
-            const int m = gr / hw;
+            const int m = w2c_fastdiv(gr, hw, p.mg_hw);              // (rows < 2^29, hw <= rows: exact; round 6)
             const int rem = gr - m * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int oy = w2c_fastdiv(rem, p.Wo, p.mg_wo), ox = rem - oy * p.Wo;
             a_iy0[i] = oy * p.stride - p.pad;
             a_ix0[i] = ox * p.stride - p.pad;
             a_base[i] = (int)(((long)m * p.H * p.W + (long)a_iy0[i] * p.W + a_ix0[i]) * p.xcs * 2 + lhi * 16);
@@ -2395,6 +2402,9 @@ int fill_args(ConvArgs& a, const void* x, int M, int H, int W, int Cin, int x_cs
         (size_t)M * a.Ho * a.Wo >= (1ull << 29))
         return W2C_E_ARG;
     a.rows = M * a.Ho * a.Wo;
+    a.mg_hw = w2c_magic((unsigned)(a.Ho * a.Wo));
+    a.mg_wo = w2c_magic((unsigned)a.Wo);
+    a.mg_ntn = a.mg_qn = a.mg_tx = a.mg_txy = 0;
     a.dbg = nullptr;
     a.span = g_span_next;            // (w2c_debug_conv_span: the next conv call of this thread records its launch span)
     g_span_next = nullptr;
