@@ -122,6 +122,17 @@ struct ConvArgs {
 };
 static inline unsigned w2c_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 __device__ __forceinline__ int w2c_fastdiv(int n, int d, unsigned magic) { return d <= 1 ? n : (int)__umulhi((unsigned)n, magic); }
+// any 0 <= n < 2^31: floor(2^32 / d) under-estimates the quotient by at most 2 -- two conditional corrections (the persistent kernels'
+// tile-run bounds: n = workgroup * tiles, far above the range of the one-multiply form)
+static inline unsigned w2c_magic_floor(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d); }
+__device__ __forceinline__ int w2c_fastdiv2(int n, int d, unsigned magic) {
+    if (d <= 1) return n;
+    int q = (int)__umulhi((unsigned)n, magic);
+    int r = n - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r >= d) ++q;
+    return q;
+}
 
 // element size / channels per K-step of the two operand types: a K-step is always ONE 128-byte run per row
 template <bool F8> struct OpT { static constexpr int ES = F8 ? 1 : 2; static constexpr int CK = F8 ? 128 : 64; };

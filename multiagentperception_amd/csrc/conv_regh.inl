@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_regh_kernel(ConvArgs p) {
     const int nwg = gridDim.x;
     const int b = blockIdx.x;
     const int logical = (nwg % 8 == 0) ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
-    const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long)logical * T) / nwg));
-    const int t_end = __builtin_amdgcn_readfirstlane((int)(((long)(logical + 1) * T) / nwg));
+    // (round 6: multiply-high divisions -- (logical + 1) * T < 2^31 is checked by the launcher; two 64-bit run-time divisions here were
+    //  ~0.3 us in front of the workgroup's first memory request)
+    const int t_begin = __builtin_amdgcn_readfirstlane(w2c_fastdiv2(logical * T, nwg, p.mg_ntn));
+    const int t_end = __builtin_amdgcn_readfirstlane(w2c_fastdiv2((logical + 1) * T, nwg, p.mg_ntn));
     if (t_begin >= t_end) { span_stamp(p, true); return; }      // workgroup-uniform: nobody is left waiting at a barrier
 
     // ---- weights -> registers: this wave's 32 channels x 576, fragment order (block (g, ch, tap, kc) = 1 KB, lane-linear) ----
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_regh_kernel(ConvArgs p) {
         for (int kc = 0; kc < 4; ++kc) foff[kx][kc] = (kc << 5) ^ ((((((l31 & 15) + kx) >> 1) ^ lhi) & 7) << 4);
     const char* const ssd = reinterpret_cast<const char*>(ss) + (ch * 8 + lhi) * 32;        // + j * 64: quad 8 ch + 2 j + lhi
 
-    int img = t_begin / tpi, y0, x0;
+    int img = w2c_fastdiv2(t_begin, tpi, p.mg_txy), y0, x0;
     {
         const int r = t_begin - img * tpi;
-        const int tx = r / nty;                    // column-major: consecutive tiles are vertically adjacent
+        const int tx = w2c_fastdiv2(r, nty, p.mg_tx);   // column-major: consecutive tiles are vertically adjacent
         x0 = tx * 16;
         y0 = (r - tx * nty) * 8;
     }
@@ -316,6 +318,10 @@ int launch_regh(ConvArgs& a, int groups, hipStream_t s) {
     const int opt = w2c_option(W2C_OPT_REGH_WGS);
     if (opt > 0) wgs = opt;
     if (wgs > tiles) wgs = tiles;
+    if ((wgs + 1) * tiles >= (1ll << 31)) return W2C_E_ARG;                  // (the kernel's 32-bit tile-run arithmetic)
+    a.mg_ntn = w2c_magic_floor((unsigned)wgs);                                // divisors of the kernel's run decode: workgroups,
+    a.mg_txy = w2c_magic_floor((unsigned)((a.H / 8) * (a.W / 16)));           // tiles per image,
+    a.mg_tx = w2c_magic_floor((unsigned)(a.H / 8));                           // tile rows (column-major tile order)
     hipLaunchKernelGGL((conv3x3_c64_regh_kernel<HAS_RES, NBUF, RES_STEP, OPT>), dim3((unsigned)wgs, groups), dim3(256), lds, s, a);
     return w2c_launch_status();
 }

@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_regh_kernel(ConvArgs p) 
     const int nwg = gridDim.x;
     const int b = blockIdx.x;
     const int logical = (nwg % 8 == 0) ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
-    const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long)logical * T) / nwg));
-    const int t_end = __builtin_amdgcn_readfirstlane((int)(((long)(logical + 1) * T) / nwg));
+    // (round 6: multiply-high divisions -- (logical + 1) * T < 2^31 is checked by the launcher; two 64-bit run-time divisions here were
+    //  ~0.3 us in front of the workgroup's first memory request)
+    const int t_begin = __builtin_amdgcn_readfirstlane(w2c_fastdiv2(logical * T, nwg, p.mg_ntn));
+    const int t_end = __builtin_amdgcn_readfirstlane(w2c_fastdiv2((logical + 1) * T, nwg, p.mg_ntn));
     if (t_begin >= t_end) { span_stamp(p, true); return; }      // workgroup-uniform
 
     // ---- weights -> registers, fragment order (w2c_pack_wfrag_bf16 / ops.pack_w1frag): block (g, w, tap, kc) = 1 KB, lane-linear.
@@ -156,10 +158,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_regh_kernel(ConvArgs p) 
     const char* const ssd1 = reinterpret_cast<const char*>(ss) + (wave * 8 + lhi) * 32;        // + j * 64: quad 8 w + 2 j + lhi
     const char* const ssd2 = ssd1 + 1024;
 
-    int img = t_begin / tpi, oy0, ox0;
+    int img = w2c_fastdiv2(t_begin, tpi, p.mg_txy), oy0, ox0;
     {
         const int rr = t_begin - img * tpi;
-        const int ty = rr / ntx;
+        const int ty = w2c_fastdiv2(rr, ntx, p.mg_tx);
         oy0 = ty * 8;
         ox0 = (rr - ty * ntx) * 8;
     }
@@ -320,6 +322,10 @@ int launch_s2regh(ConvArgs& a, int groups, hipStream_t s) {
     const int opt = w2c_option(W2C_OPT_REGH_WGS);
     if (opt > 0) wgs = opt;
     if (wgs > tiles) wgs = tiles;
+    if ((wgs + 1) * tiles >= (1ll << 31)) return W2C_E_ARG;                  // (the kernel's 32-bit tile-run arithmetic)
+    a.mg_ntn = w2c_magic_floor((unsigned)wgs);
+    a.mg_txy = w2c_magic_floor((unsigned)((a.Ho / 8) * (a.Wo / 8)));
+    a.mg_tx = w2c_magic_floor((unsigned)(a.Wo / 8));
     hipLaunchKernelGGL((conv3x3s2_c64_regh_kernel<0>), dim3((unsigned)wgs, groups), dim3(256), lds, s, a);
     return w2c_launch_status();
 }
