@@ -288,8 +288,11 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
     // The weights of stages 1 and 2 do not depend on the activations: this thread's 32 + 16 values are requested up front, so that their
     // memory round trips run under stage 0's instead of two more behind it (three dependent round trips -> one; the dispatched shape:
     // K1 / (1024 / H1) == 32).  Same values, same fmaf order.
-    const int P1 = 1024 / H1, j1 = tid % H1, p1 = tid / H1;
-    const int kn1 = (K1 - p1 + P1 - 1) / P1;
+    // K1 and H1 divide 1024 (the launcher's condition for this kernel): powers of two -- every division below is a shift (round 6: eight
+    // per-lane run-time divisions were ~0.5 us of this 8 us launch at the end of the policy chain)
+    const int shH = __builtin_ctz((unsigned)H1), shK = __builtin_ctz((unsigned)K1);
+    const int P1 = 1024 >> shH, j1 = tid & (H1 - 1), p1 = tid >> shH;
+    const int kn1 = (K1 - p1 + P1 - 1) >> (10 - shH);
     const bool pre = kn1 == 32;
     float wv1[32], wv2[16];
     if (pre) {
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
         }
     }
     {   // stage 0: h0[k] = relu(sum_p part_p[m][col_off + k] + b0): thread = (k, group of n_part / G consecutive partials)
-        const int G = 1024 / K1, per = n_part / G;
-        const int k = tid % K1, g = tid / K1;
+        const int G = 1024 >> shK, per = n_part >> (10 - shK);
+        const int k = tid & (K1 - 1), g = tid >> shK;
         const float* src = part + (size_t)m * h0_stride + s.col_off + k + (size_t)g * per * part_stride;
         float v = 0.f;
         int pp = 0;
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(1024) void head_tail2w_kernel(const float* __restri
         __syncthreads();
     }
     {   // stage 1: h1 = relu(W1 h0 + b1): thread = (output j, K partition): k = p + i P
-        const int P = 1024 / H1, j = tid % H1, p = tid / H1;
-        const int kn = (K1 - p + P - 1) / P;
+        const int P = 1024 >> shH, j = tid & (H1 - 1), p = tid >> shH;
+        const int kn = (K1 - p + P - 1) >> (10 - shH);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         int i = 0;
         if (pre) {
@@ -773,7 +776,9 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
     const int id0 = blockIdx.x * 256 + threadIdx.x;
     f32x4_t uk0[8];
     if (N <= 8 && id0 < hw * CGp) {
-        const int px = id0 / CGp, cg = id0 - px * CGp;
+        // (C / 4 is a power of two for every decoder of the path: a shift instead of a per-lane run-time division in front of the launch's
+        //  first loads; any other width takes the division)
+        const int px = (CGp & (CGp - 1)) == 0 ? id0 >> __builtin_ctz((unsigned)CGp) : id0 / CGp, cg = id0 - px * CGp;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             uk0[k] = k < N ? *reinterpret_cast<const f32x4_t*>(u + ((size_t)(k * B + b) * hw + px) * ucs + cg * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -809,8 +814,10 @@ __global__ __launch_bounds__(256) void graph_fuse_u_kernel(const float* __restri
     }
     const int CG = C >> 2;
     const int total = hw * CG;
+    const bool cg_p2 = (CG & (CG - 1)) == 0;
+    const int cg_sh = __builtin_ctz((unsigned)CG);
     for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
-        const int px = id / CG, cg = id - px * CG;
+        const int px = cg_p2 ? id >> cg_sh : id / CG, cg = id - px * CG;
         const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + cg * 4);
         if (N <= 8) {
             // small graphs (cfg 2: 5 agents): all keys' 16 bytes in flight together; a key no query uses is not loaded (wave-uniform)
