@@ -43,6 +43,12 @@ def set_label_check_collective(enabled, group=None):
     return prev
 
 
+def restore_label_check_collective(prev):
+    """put back what set_label_check_collective returned"""
+    global _label_check_group
+    _label_check_group = prev
+
+
 def _note_bad_labels(out3):
     """Off the hot path: the count is added on the device (no sync), and read back on the first call, then every
     _LABEL_CHECK_EVERY calls.  The error names the range of calls it covers.  The check is local to the rank: the loss issues no

@@ -103,6 +103,33 @@ class SlotRef:
         return True
 
 
+# The collector is process-global and capture windows may be open on several threads (thread-local capture mode, DataParallel replicas):
+# it is switched off when the FIRST window opens and back on (if it was on) when the LAST one closes (two threads toggling it
+# independently re-enabled it inside the other's window).
+_gc_lock = threading.Lock()
+_gc_depth = 0
+_gc_was_on = False
+
+
+def _gc_hold():
+    import gc
+    global _gc_depth, _gc_was_on
+    with _gc_lock:
+        if _gc_depth == 0:
+            _gc_was_on = gc.isenabled()
+            gc.disable()
+        _gc_depth += 1
+
+
+def _gc_release():
+    import gc
+    global _gc_depth
+    with _gc_lock:
+        _gc_depth -= 1
+        if _gc_depth == 0 and _gc_was_on:
+            gc.enable()
+
+
 class capture:
     """`with ops.capture() as graph:` -- capture the launches of the block into a fresh torch.cuda.CUDAGraph (thread-local error mode) with
     Python's cyclic garbage collector held off for the length of the window.
@@ -125,23 +152,19 @@ class capture:
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        self._gc_was_on = gc.isenabled()
-        gc.disable()
+        _gc_hold()
         try:
             self._ctx.__enter__()
         except BaseException:
-            if self._gc_was_on:
-                gc.enable()
+            _gc_release()
             raise
         return self.graph
 
     def __exit__(self, et, ev, tb):
-        import gc
         try:
             return self._ctx.__exit__(et, ev, tb)
         finally:
-            if self._gc_was_on:
-                gc.enable()
+            _gc_release()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -423,8 +446,7 @@ def record_program(dev, fn, warmup=2, before_warmup=None):
     # (see ops.capture)
     gc.collect()
     torch.cuda.synchronize(dev)
-    gc_was_on = gc.isenabled()
-    gc.disable()
+    _gc_hold()
     rec = _Recorder(dev)
     _tls.recorder = rec
     ok = False
@@ -440,8 +462,7 @@ def record_program(dev, fn, warmup=2, before_warmup=None):
                 rec._close(abort=True)
             except Exception:                       # noqa: BLE001
                 pass
-        if gc_was_on:
-            gc.enable()
+        _gc_release()
     return Program(dev, rec.prog, res)
 
 

@@ -473,6 +473,10 @@ def _sharded_loss(loss_fn, pred, labels_local, group):
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
         d = tot[0].clamp_min(1e-30)
         return local_sum / d.float(), (tot[1] / d).float()
+    if base is not None and getattr(base, "__name__", "") in ("cross_entropy2d", "multi_scale_cross_entropy2d"):
+        import warnings
+        warnings.warn("agent-parallel training: %s with these keywords is averaged as the mean of the ranks' losses, which differs from the "
+                      "unsharded loss when ignored pixels or class weights differ across ranks" % base.__name__, stacklevel=2)
     local = loss_fn(pred, labels_local)
     g = local.detach().clone().float().reshape(1)
     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
@@ -484,14 +488,19 @@ def agent_parallel_train_step(model, optimizer, loss_fn, inputs_local, labels_lo
     size_average loss over every rank's pixels with the global denominator, see _sharded_loss).
     labels_local: the labels of this rank's agents, agent-major [n_loc*B, H, W].  The caller's sync-BN setting is restored on exit;
     a train-mode BatchNorm that cannot take the synchronised HIP path raises (train_ops.bn_act) instead of normalising locally."""
+    from . import loss as _loss
     from . import train_ops
     prev = train_ops.set_sync_bn(True, group)
+    # every rank calls the loss the same number of times here, so the out-of-range-label check may be collective: a bad label on ONE
+    # rank raises on ALL of them instead of leaving its peers blocked in the gradient all-reduce (ADVICE r05)
+    prev_chk = _loss.set_label_check_collective(True, group)
     try:
         optimizer.zero_grad(set_to_none=True)
         pred, _ = agent_parallel_train_forward(model, inputs_local, group)
         term, global_loss = _sharded_loss(loss_fn, pred, labels_local, group)
         term.backward()
     finally:
+        _loss.restore_label_check_collective(prev_chk)
         train_ops.restore_sync_bn(prev)
     params = [p for p in model.parameters() if p.grad is not None]
     if params:
