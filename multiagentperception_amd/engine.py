@@ -775,9 +775,8 @@ class CommEngine:
     # front: six host-issued launches) -> fork -> the policy chain (layer2..4, squeezer, policy conv1..5, heads) as ONE single-branch HIP
     # graph on the caller's stream || the value chain (layer2..4, squeezer, decoder conv0 of the value maps) as ONE single-branch graph
     # on lane 1 -> join -> graph + fusion -> decoder's last conv -> x32 upsample (three host-issued launches), with two event edges.
-    # The stem reads the caller's tensor and the upsample writes the caller-owned output through device-resident pointer slots
-    # (include/w2c_hip.h "indirect operands"): per forward one slot-setting launch + one replay of the program.
-    _SLOT_X, _SLOT_OUT, _SLOT_PACK, _SLOT_GT, _SLOT_HIST = 0, 1, 2, 3, 4
+    # The stem reads the caller's tensor and the upsample writes the caller-owned output as plain kernel arguments of those host-issued
+    # launches: nothing is copied and nothing but the replay is launched.
 
     def _out_like(self, x, N, labels, confusion):
         """(shape, dtype) of the first return value: f32 logits [N*B, n_cls, H, W], u8 labels [N*B, H, W], or None"""
@@ -799,51 +798,45 @@ class CommEngine:
         if entry is None:
             entry = self._record(x, B, N, mode, labels, confusion, out)
             _lru_put(self._graphs, key, entry)
-        program, slots = entry
+        program, io = entry
         packc = torch.empty_like(program.result)
-        ops.set_slots(slots, [x, out, packc, gt, hist])
+        io.update(x=x, out=out, pack=packc, gt=gt, hist=hist)     # what the host-issued regions of this replay read and write
         program.replay()
+        io.update(x=None, out=None, pack=None, gt=None, hist=None)
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, N)
         return out, prob, action, nnz
 
     def _record(self, x, B, N, mode, labels, confusion, out):
+        """The caller-owned tensors -- frames in, logits / labels / histogram / packed prob | action | nnz out -- are touched by the
+        host-issued regions only (the stem at the head of the front, the fusion and the upsample behind the join): they take this
+        replay's tensors as plain kernel arguments from `io`.  (Rounds 4-5, everything inside one graph: the same tensors went through
+        device-resident pointer slots filled by one more launch in front of every replay.)"""
         dev = x.device
-        slots = torch.zeros(8, dtype=torch.int64, device=dev)
-        xs = ops.SlotRef(slots, self._SLOT_X, x)
-        outs = None if out is None else ops.SlotRef(slots, self._SLOT_OUT, out)
         gt, hist = confusion if confusion is not None else (None, None)
-        gts = None if gt is None else ops.SlotRef(slots, self._SLOT_GT, gt)
-        hists = None if hist is None else ops.SlotRef(slots, self._SLOT_HIST, hist)
+        io = dict(x=x, out=out, pack=None, gt=gt, hist=None)
 
         def whole():
-            s0 = ops.lanes(dev).eager_static(lambda: self.trunk.stem(xs, N))      # (host-issued, see TrunkPlan.after_stem)
+            s0 = ops.lanes(dev).eager_static(lambda: self.trunk.stem(io["x"], N))      # (host-issued, see TrunkPlan.after_stem)
             _, u, keys, querys = self.encode_from_stem(s0)
-            pack2 = ops.SlotRef(slots, self._SLOT_PACK, ops.graph_outputs(dev, B, N, N)[0])
 
             def join():
-                low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode, pack2=pack2)
+                low, prob, action, nnz = self.graph_and_low(u, keys, querys, B, N, 0, N, mode, pack2=io["pack"])
                 if confusion is not None:
-                    ops.upsample32_argmax_confusion(low, self.n_classes, gts, hists, want_labels=labels, out=outs,
+                    ops.upsample32_argmax_confusion(low, self.n_classes, io["gt"], io["hist"], want_labels=labels, out=io["out"],
                                                     ws=self._confusion_ws(low.device))
                 elif labels:
-                    ops.upsample32_argmax(low, self.n_classes, out=outs)
+                    ops.upsample32_argmax(low, self.n_classes, out=io["out"])
                 else:
-                    ops.upsample_bilinear32(low, self.n_classes, out=outs)
+                    ops.upsample_bilinear32(low, self.n_classes, out=io["out"])
             ops.lanes(dev).eager(join)              # the three launches behind the join: host-issued at every replay (TrunkPlan.after_stem)
             return self._last_pack
 
-        scratch = []                                # what the warm-up forwards write through the slots: alive until they have run
-
-        def point_slots():
-            # warm-up on real targets (function attributes, head plans, the allocator).  The caller's confusion histogram is NOT
-            # touched: the warm-up forwards accumulate into a scratch copy.
-            scratch.append(ops.graph_outputs(dev, B, N, N)[0])
-            scratch.append(None if hist is None else torch.zeros_like(hist))
-            ops.set_slots(slots, [x, out, scratch[0], gt, scratch[1]])
-
-        program = ops.record_program(dev, whole, warmup=2, before_warmup=point_slots)
-        del scratch[:]                              # (record_program synchronised the device after the warm-up)
-        return program, slots
+        # warm-up and recording run on real targets (function attributes, head plans, the allocator) -- except the caller's confusion
+        # histogram: the warm-up forwards and the recording (whose host-issued regions execute) accumulate into a scratch copy
+        io["pack"] = ops.graph_outputs(dev, B, N, N)[0]
+        io["hist"] = None if hist is None else torch.zeros_like(hist)
+        program = ops.record_program(dev, whole, warmup=2)
+        return program, io
 
 
 class SingleEngine:

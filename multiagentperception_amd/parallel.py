@@ -264,10 +264,11 @@ class AgentParallelForward:
         rows = n_loc * B
         out = torch.empty((n_loc * B, eng.n_classes, H, W), dtype=torch.float32, device=dev)
 
-        def step(xs, outs, packs):
+        def step(io):
+            # io: this run's caller-owned tensors; the host-issued regions (stem, join) read them at every replay as plain arguments
             L = ops.lanes(dev)
             works = []
-            L.eager(lambda: eng.trunk.stem(xs, n_loc, out=st.s0))      # host-issued at every replay (engine.TrunkPlan.after_stem says why)
+            L.eager(lambda: eng.trunk.stem(io["x"], n_loc, out=st.s0))      # host-issued at every replay (engine.TrunkPlan.after_stem says why)
 
             def value_tail(v):
                 # (lane 1) U first, K behind it: the process group runs its collectives in issue order on ONE internal stream, so the K
@@ -291,8 +292,8 @@ class AgentParallelForward:
                     exchange_wait(works.pop(0))
             def join():
                 wait_all()
-                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=packs, u_own=st.u_own)
-                ops.upsample_bilinear32(low, eng.n_classes, out=outs)
+                low, prob, action, nnz = eng.graph_and_low(st.v_all, st.k_all, st.q_loc, B, N, q_lo, n_loc, inference, pack2=io["pack"], u_own=st.u_own)
+                ops.upsample_bilinear32(low, eng.n_classes, out=io["out"])
             L.eager(join)
             return eng._last_pack
 
@@ -301,23 +302,19 @@ class AgentParallelForward:
         if not use_graph:
             self.launch_form = "eager"
             packc = ops.graph_outputs(dev, B, N, n_loc)[0]
-            step(x, out, packc)
+            step(dict(x=x, out=out, pack=packc))
             prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
             return out, prob, action, nnz
         ent = st.graphs.get("whole:" + inference)
         if ent is None:
-            slots = torch.zeros(8, dtype=torch.int64, device=dev)
-            xs = ops.SlotRef(slots, 0, x)
-            outs = ops.SlotRef(slots, 1, out)
-            like = ops.graph_outputs(dev, B, N, n_loc)[0]
-            packs = ops.SlotRef(slots, 2, like)
-            program = ops.record_program(dev, lambda: step(xs, outs, packs), warmup=2,
-                                         before_warmup=lambda: ops.set_slots(slots, [x, out, like]))
-            ent = st.graphs["whole:" + inference] = (program, slots)
-        program, slots = ent
+            io = dict(x=x, out=out, pack=ops.graph_outputs(dev, B, N, n_loc)[0])
+            program = ops.record_program(dev, lambda: step(io), warmup=2)
+            ent = st.graphs["whole:" + inference] = (program, io)
+        program, io = ent
         packc = torch.empty_like(program.result)
-        ops.set_slots(slots, [x, out, packc])
+        io.update(x=x, out=out, pack=packc)
         program.replay()
+        io.update(x=None, out=None, pack=None)
         self.launch_form = "one program: %d single-branch hip-graphs + %d host-issued steps incl. the RCCL all-gathers" % (program.n_graphs, program.n_calls)
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
         return out, prob, action, nnz
