@@ -368,7 +368,9 @@ class TrunkPlan:
         # value chain on lane 0 1.047-1.051 ms (eager 1.032-1.036), policy chain on lane 0 1.027-1.038 (eager 1.021-1.026).
         # (Measured and not kept: the policy chain as two row-sliced half-batch chains on two lanes, each launch half the workgroups --
         # eager 1.058 vs 1.034, recorded program 1.35 ms: three chains contend for the same slots and the program's third stream shares a
-        # hardware pipe.  profiles/r05_policy_tail.txt: the policy chain's launches at s_setprio 3 make BOTH chains slower.)
+        # hardware pipe.  profiles/r05_policy_tail.txt: the policy chain's launches at s_setprio 3 make BOTH chains slower.  The policy
+        # chain host-issued too, leaving the value chain as the only graph: 0.9699 / 0.9706 / 0.9714 against 0.9688 / 0.9718 / 0.9720 ms --
+        # equal, at twice the host time: 0.47-0.51 ms per forward against 0.25-0.27.)
         pol_map = None if policy_next is None else (sq if squeezer_out is None else squeezer_out[1])
         state = None
         with L.on(1, after=(0,)):

@@ -1351,9 +1351,9 @@ def head_tail2(h0, k1, tail_a, tail_b, out_a=None, out_b=None):
     if min(ca, cb) < 0 or max(ca, cb) + k1 > stride or w1a.shape[0] != k1 or w1b.shape[0] != k1:
         raise W2CError("head_tail2: column ranges / weights do not fit h0 %s" % (tuple(h0.shape),))
     if out_a is None:
-        out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
+        out_a = _empty((M, w2a.shape[1]), torch.float32, dev)
     if out_b is None:
-        out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
+        out_b = _empty((M, w2b.shape[1]), torch.float32, dev)
     for o, w2 in ((out_a, w2a), (out_b, w2b)):
         if tuple(o.shape) != (M, w2.shape[1]) or o.dtype != torch.float32 or not o.is_contiguous() or o.device != dev:
             raise W2CError("head_tail2: bad preallocated output %s" % (tuple(o.shape),))
@@ -1387,7 +1387,7 @@ def head_fc0_mfma(x, x_stride, M, K, wfrag, O, ksplit=HEAD_FC0_KSPLIT, part=None
     if x.dtype != BF16 or wfrag.dtype != torch.float32:
         raise W2CError("head_fc0_mfma: x must be bf16, wfrag f32")
     if part is None:
-        part = torch.empty((ksplit, M, O), dtype=torch.float32, device=dev)
+        part = _empty((ksplit, M, O), torch.float32, dev)
     with torch.cuda.device(dev):
         check(_native.lib().w2c_head_fc0_mfma_f32(_p(x), x_stride, M, K, _p(wfrag), O, ksplit, _p(part), _stream(dev)),
               "w2c_head_fc0_mfma_f32")
@@ -1404,9 +1404,9 @@ def head_tail2_parts(part, b0, k1, tail_a, tail_b, out_a=None, out_b=None):
     if w1b.shape[1] != H1 or min(ca, cb) < 0 or max(ca, cb) + k1 > stride or w1a.shape[0] != k1 or w1b.shape[0] != k1:
         raise W2CError("head_tail2_parts: column ranges / weights do not fit %s" % (tuple(part.shape),))
     if out_a is None:
-        out_a = torch.empty((M, w2a.shape[1]), dtype=torch.float32, device=dev)
+        out_a = _empty((M, w2a.shape[1]), torch.float32, dev)
     if out_b is None:
-        out_b = torch.empty((M, w2b.shape[1]), dtype=torch.float32, device=dev)
+        out_b = _empty((M, w2b.shape[1]), torch.float32, dev)
     for o, w2 in ((out_a, w2a), (out_b, w2b)):
         if tuple(o.shape) != (M, w2.shape[1]) or o.dtype != torch.float32 or not o.is_contiguous() or o.device != dev:
             raise W2CError("head_tail2_parts: bad preallocated output %s" % (tuple(o.shape),))
