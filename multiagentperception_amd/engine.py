@@ -335,24 +335,7 @@ class TrunkPlan:
         # the all-eager forward at a third of its host time (round 6, tools/r06/ab.sh, ms per forward, interleaved:
         # all four segments as graphs 1.0136 / 1.0084 / 1.0085, join eager 1.0027 / 0.9979 / 1.0004; then on another box join eager
         # 1.0678 / 1.0732 / 1.0680, front eager too 1.0602 / 1.0644 / 1.0612; all-eager forwards of the same jobs 1.000-1.011 / 1.058-1.067).
-        import os as _os
-        _pf = int(_os.environ.get("W2C_X_PF", "0"))
-        if _pf:
-            plans0 = self._single_trunk_plans(0)
-            Tw = [torch.empty_like(p_in) for _ in range(split_from)]
-            Qw = [torch.empty_like(p_in) for _ in range(split_from)]
-
-            def layer1(g):
-                q = p_in
-                for bi in range(split_from):
-                    c1, c2, _ = plans0[g][0][bi]
-                    t = c1.run(q, x_ch_off=64 * g, out=Tw[bi], out_ch_off=64 * g)
-                    q = c2.run(t, x_ch_off=64 * g, residual=q, out=Qw[bi], out_ch_off=64 * g)
-                return q
-            front = None
-            p = Qw[-1]
-        else:
-            p, front = L.eager_static(pre_fork)
+        p, front = L.eager_static(pre_fork)
         feat = self.squeezer.cout
         M, Hs, Ws, _ = p.shape
         for _, _, ds in self.blocks[split_from:]:
@@ -390,16 +373,10 @@ class TrunkPlan:
         # equal, at twice the host time: 0.47-0.51 ms per forward against 0.25-0.27.)
         pol_map = None if policy_next is None else (sq if squeezer_out is None else squeezer_out[1])
         state = None
-        if _pf == 1:
-            L.eager_static(lambda: layer1(1))
         with L.on(1, after=(0,)):
-            if _pf:
-                layer1(0)
             chain(0)
             vres = value_next(sq if squeezer_out is None else squeezer_out[0]) if value_next is not None else None
             _stamp(26)
-        if _pf == 2:
-            L.eager_static(lambda: layer1(1))
         chain(1)
         if policy_next is not None:                # the policy chain goes straight on (policy convs, heads) beside the value chain
             state = policy_next[0](pol_map)

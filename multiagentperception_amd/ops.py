@@ -861,8 +861,8 @@ def conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, residual=N
         out = _empty((M, H, W, out_cstride), dtype=BF16, device=dev)
     if tuple(out.shape) != (M, H, W, out_cstride) or out.dtype != BF16:
         raise W2CError("conv3x3_wreg: bad out tensor")
-    if residual is not None and tuple(residual.shape) != tuple(out.shape):
-        raise W2CError("conv3x3_wreg: residual geometry must equal the output geometry")      # (read at the output's channel window)
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or out_ch_off):
+        raise W2CError("conv3x3_wreg: residual geometry must equal the output geometry")
     if x_ch_off < 0 or x_ch_off + groups * cin > xcs or out_ch_off % 8 or out_ch_off + (1 if _gstride else groups) * cout > out_cstride:
         raise W2CError("conv3x3_wreg: channel window outside the tensor")
     per_img = max(H * W * xcs * 2, H * W * out_cstride * 2)
@@ -877,8 +877,7 @@ def conv3x3_wreg(x, x_ch_off, cin, wfrag, cout, groups, scale, shift, residual=N
     tok = timer.begin(dev) if timer is not None else None
     with torch.cuda.device(dev):
         check(_native.lib().w2c_conv3x3_wreg_bf16(x.data_ptr() + 2 * x_ch_off, M, H, W, cin, xcs, _p(wfrag), cout, groups,
-                                                  _p(scale), _p(shift), None if residual is None else residual.data_ptr() + 2 * out_ch_off,
-                                                  1 if relu else 0,
+                                                  _p(scale), _p(shift), _p(residual), 1 if relu else 0,
                                                   out.data_ptr() + 2 * out_ch_off, out_cstride, int(_gstride), int(form), _stream(dev)),
               "w2c_conv3x3_wreg_bf16")
     if timer is not None:
