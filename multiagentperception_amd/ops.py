@@ -200,7 +200,8 @@ def _new_side_stream(dev):
 
 
 def _lane_stream(dev, k):
-    """long-lived side stream k (>= 1) of this thread on `dev` (eager executor; a Program owns its own set)"""
+    """long-lived side stream `k` of this thread on `dev`: lanes 1.. of the eager executor AND of every Program this thread records (Program.__init__ says why
+    they are shared), the recorder's capture streams, the warm-up stream"""
     st = _tls.__dict__.setdefault("lane_streams", {})
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), k)
     s = st.get(key)
@@ -270,6 +271,14 @@ class _LaneCtx:
         return False
 
 
+class _CapStreams:
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __getitem__(self, lane):
+        return _lane_stream(self.dev, "cap%d" % lane)
+
+
 class _Recorder:
     """record_program()'s executor: one capture window open at any time, on the current lane; every verb closes it, notes the edge and
     opens the next one.  Each window becomes its own CUDAGraph with its own private memory pool (blocks freed inside a window are
@@ -280,7 +289,8 @@ class _Recorder:
     def __init__(self, dev):
         self.dev = dev
         self.prog = []
-        self.cap = [torch.cuda.Stream(device=dev) for _ in range(_MAX_LANES)]     # capture-time streams (replay uses the Program's)
+        self.cap = _CapStreams(dev)                 # capture-time streams: long-lived, per thread, made when a lane is first used (every
+                                                    # stream ever made keeps its share of one of the runtime's four hardware queues)
         self._lane, self._g, self._sctx = 0, None, None
         self.dirty = False
         self.n_events = 0
@@ -393,13 +403,20 @@ def lanes(dev):
 
 class Program:
     """A recorded forward: single-branch graphs + the edges between them (see the block comment above).  replay() issues it on the
-    caller's current stream (lane 0) and this Program's own side streams; `result` is what the recorded function returned (tensors in
+    caller's current stream (lane 0) and the recording thread's lane streams; `result` is what the recorded function returned (tensors in
     the graphs' private pools: static across replays)."""
 
     def __init__(self, dev, prog, result):
         self.dev, self.prog, self.result = dev, prog, result
         n_side = max([st[1] for st in prog] + [st[2] for st in prog if st[0] == "sync"] + [0])
-        self.side = [_new_side_stream(dev) for _ in range(n_side)]
+        # the side lanes are the recording thread's long-lived lane streams, SHARED by every Program it records (and by its eager forwards):
+        # a process that keeps several forwards in flight (one engine per caller stream, bench.py's forwards_in_flight) then runs on
+        # callers + 1 streams instead of 2 per engine -- beyond the runtime's four hardware queues streams share a pipe and one engine's
+        # chains queue behind another's (3 engines in flight, ms per forward, same box: own side streams 1.097 / 1.102, shared 0.992 /
+        # 0.993; one forward at a time 0.986 either way).  Sharing a lane orders the value chains of consecutive forwards one behind the
+        # other, which they are anyway; no cycle can form (a lane's work waits for caller-stream events only, never the reverse before
+        # its own join)
+        self.side = [_lane_stream(dev, k + 1) for k in range(n_side)]
         self.n_graphs = sum(1 for st in prog if st[0] == "graph")
         self.n_calls = sum(1 for st in prog if st[0] == "call")
 
@@ -434,7 +451,7 @@ def record_program(dev, fn, warmup=2, before_warmup=None):
     if getattr(_tls, "recorder", None) is not None:
         raise W2CError("record_program inside a recording")
     if warmup > 0:
-        side = torch.cuda.Stream(device=dev)
+        side = _lane_stream(dev, "cap0")              # (nothing is being captured during the warm-up forwards)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             if before_warmup is not None:
