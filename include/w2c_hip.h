@@ -124,6 +124,8 @@ int w2c_conv_igemm_bf16_variant(const uint16_t* x, int M, int H, int W, int Cin,
  *                               layer geometry only, never of M), else 0
  *   w2c_conv3x3_wreg_bf16    : form 0 = the library's choice; 80 / 81 / 83 = 2x2 / 1x4 / 1x2 waves (channel blocks x K groups);
  *                               93 / 94 = 81 with the weight loads 4 / 2 K-steps ahead instead of 8 (93 is the default form).
+ *                               95 = 93 with 32 output channels per wave instead of 64 (twice the workgroups; bit-identical): what form 0
+ *                               picks for launches of <= 128 workgroups, where 93's workgroups would leave half of the chip empty.
  * Requires H % 8 == 0, W % 16 == 0, Cin % 64 == 0, Cout % 64 == 0 (form 80: % 128), 16-byte aligned rows. */
 int w2c_pack_wfrag_bf16(const uint16_t* w, uint16_t* wfrag, int groups, int Cout, int Cin, w2c_stream_t stream);
 int w2c_conv3x3_wreg_supported(int H, int W, int Cin, int Cout);

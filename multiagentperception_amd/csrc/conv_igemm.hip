@@ -2300,6 +2300,8 @@ int launch_variant(int variant, ConvArgs& a, int groups, hipStream_t s) {
         case 93: return launch_wreg<1, 4, 0, 4>(a, groups, s);   // 81 with the weights 4 / 2 K-steps ahead instead of 8
         case 94: return launch_wreg<1, 4, 0, 2>(a, groups, s);
         case 193: return launch_wreg<1, 4, 0, 4, 2, true>(a, groups, s);      // 93 writing f32 (w2c_conv3x3_wreg_f32out)
+        case 95: return launch_wreg<1, 4, 0, 4, 1>(a, groups, s);             // 93 with 32 channels per wave: twice the workgroups (bit-identical)
+        case 195: return launch_wreg<1, 4, 0, 4, 1, true>(a, groups, s);
         // (round 4, removed in round 5: 32 channels per wave -- 8 waves on the same workgroup tile, bit-identical -- for the small launches:
         //  +-8 % alone, slower in every forward (profiles/r04_rank_shapes.txt): those launches are not short of waves)
         // layer1 (Cin = Cout = 64): weights stationary in registers, one persistent wave per SIMD, no barriers
@@ -2490,6 +2492,16 @@ static int wreg_form(int H, int W, int Cin, int Cout) {
     return 93;                                       // 1 channel block x 4 K groups, weights 4 K-steps ahead
 }
 extern "C" int w2c_conv3x3_wreg_supported(int H, int W, int Cin, int Cout) { return wreg_form(H, W, Cin, Cout) != 0; }
+// launches of the default form with fewer 128-pixel x 64-channel workgroups than this take the 32-channel-per-wave form (twice the
+// workgroups, same K groups and reduction order: the same bits, so the choice may depend on the image count)
+// (round 6, tools/r06/ab.sh, one rank's share of cfg 3 = 8 images, ms per forward: 0.5608 / 0.5610 -> 0.5473 / 0.5488 with the threshold at
+//  128 workgroups -- its layer4 / squeezer / policy conv launches are 64-128 workgroups of ~20 us on a 256-CU chip; 0.5537 / 0.5551 at 256,
+//  where layer3's 256-workgroup launches switch too; the sharded step of that rank 0.6129 / 0.6137 -> 0.5991 / 0.5990; cfg 4's rank 0.8966
+//  -> 0.8791; cfg 2, whose smallest launch of this family is 160 workgroups, is untouched.)
+constexpr long kWregSmallLaunch = 128;
+static bool wreg_small(int M, int H, int W, int Cout, int groups) {
+    return (long)M * (H / 8) * (W / 16) * (Cout / 64) * groups <= kWregSmallLaunch;
+}
 
 extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int Cin, int x_cstride,
                                      const uint16_t* wfrag, int Cout, int groups,
@@ -2506,8 +2518,9 @@ extern "C" int w2c_conv3x3_wreg_bf16(const uint16_t* x, int M, int H, int W, int
         return W2C_E_ARG;
     if (form == 0) {
         form = wreg_form(H, W, Cin, Cout);
+        if (form == 93 && wreg_small(M, H, W, Cout, groups)) form = 95;
     }
-    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94 && form != 54) return W2C_E_ARG;
+    if (form != 80 && form != 81 && form != 83 && form != 93 && form != 94 && form != 95 && form != 54) return W2C_E_ARG;
     w2c_clear_error();
     return launch_variant(form, a, groups, reinterpret_cast<hipStream_t>(stream));
 }
@@ -2528,7 +2541,7 @@ extern "C" int w2c_conv3x3_wreg_f32out(const uint16_t* x, int M, int H, int W, i
         (unsigned long long)(groups - 1) * (unsigned long long)(y_group_stride ? y_group_stride : Cout) + (size_t)M * H * W * y_cstride >= (1ull << 31))
         return W2C_E_ARG;
     w2c_clear_error();
-    return launch_variant(193, a, groups, reinterpret_cast<hipStream_t>(stream));
+    return launch_variant(wreg_small(M, H, W, Cout, groups) ? 195 : 193, a, groups, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" long long w2c_conv_splitk_workspace_bytes(int M, int H, int W, int Cin, int Cout, int ksize, int stride,

@@ -25,13 +25,14 @@
 //     before the exchange) + ReLU, bf16 pack, v_permlane32_swap pairs the half-waves' channel quads into 16-byte stores.
 // LDS: 72 KB of patch buffers -> two workgroups per CU; 128 AGPRs + <= 128 VGPRs -> two waves per SIMD.
 // The K order differs from the ring kernels' (partial sums per K group): results agree to f32 rounding, not bit for bit.
-// NB = 32-channel blocks per wave (2: the wave tile above; 1: 128 pixels x 32 channels -- twice the waves on the same workgroup tiles for
-// launches that cannot fill the chip's wave slots (M <= 20 tail convs, a rank's share of a sharded batch): one wave per SIMD hides none of
-// its weight-load and LDS latencies.  Same K groups, same reduction order: bit-identical to NB = 2.
+// NB = 32-channel blocks per wave (2: the wave tile above; 1: 128 pixels x 32 channels -- twice the workgroups on the same pixel tiles, for
+// launches that cannot fill the chip: <= 128 workgroups of the NB = 2 form (a rank's share of a sharded batch, Single_agent at small
+// batches) are one ~20 us workgroup life on half the CUs; the library switches by the launch's workgroup count (conv_igemm.hip
+// wreg_small).  Same K groups, same reduction order: bit-identical to NB = 2, so the choice may depend on the image count.
 // F32OUT: the output tensor is f32 (the decoder's first conv taken through the fusion by linearity: U = conv0_nobias(V), engine.DecoderPlan);
 // a lane stores its two channel quads as they sit in the accumulators (two 16-byte stores 8 channels apart): no pack, no half-wave swap.
 template <int NN, int KS, int ABL = 0, int DW = 8, int NB = 2, bool F32OUT = false>      // ABL: timing ablations (wrong results): 1 no weight loads, 2 no fragment reads
-__global__ __launch_bounds__(64 * NN * KS, NB == 1 ? 4 : 2) void conv3x3_wreg_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * NN * KS, 2) void conv3x3_wreg_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PW = 18, NP = 180, NPIECE = 23;  // patch: 10 x 18 pixels, 128 B each, DMA'd in 1 KB pieces of 8 pixels
     constexpr int NW = NN * KS;

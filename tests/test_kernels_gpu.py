@@ -1080,7 +1080,7 @@ def test_conv3x3_wreg_matches_fp32_conv(case):
 
 
 @pytest.mark.parametrize("M,H,W,cin,cout,relu,ocs,off", [(5, 16, 16, 512, 256, False, 256, 0), (3, 8, 16, 256, 64, True, 136, 8),
-                                                         (2, 16, 32, 512, 256, False, 512, 256)])
+                                                         (2, 16, 32, 512, 256, False, 512, 256), (36, 16, 16, 512, 256, False, 256, 0)])
 def test_conv3x3_wreg_f32_output_rounds_to_the_bf16_form(M, H, W, cin, cout, relu, ocs, off):
     """w2c_conv3x3_wreg_f32out (round 6: the decoder's first conv on the value maps, U = conv0 without bias): the same K groups and
     reduction order as the default bf16 form -- its f32 values ROUND to that form's bf16 output bit for bit --, within f32 summation
@@ -1092,8 +1092,8 @@ def test_conv3x3_wreg_f32_output_rounds_to_the_bf16_form(M, H, W, cin, cout, rel
     sc, sh = scale.to(_dev()), shift.to(_dev())
     out = torch.full((M, H, W, ocs), 7.0, dtype=torch.float32, device=_dev())
     y = ops.conv3x3_wreg_f32(x_dev, 0, cin, wfrag, cout, sc, sh, relu=relu, out=out, out_ch_off=off)
-    y16 = ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, relu=relu)
-    torch.cuda.synchronize()
+    y16 = ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, relu=relu, form=93)     # (the f32 entry picks the 64- or the 32-channel
+    torch.cuda.synchronize()                                                             # form by the launch size: the last case takes the former)
     win = y[..., off:off + cout]
     assert torch.equal(win.to(BF16), y16)
     ref = F.conv2d(xs[0], ws[0], None, stride=1, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
@@ -1265,15 +1265,17 @@ def test_s2_front_c64_is_independent_of_image_count_groups_and_workgroup_count_a
 
 
 def test_conv3x3_wreg_weight_lookahead_forms_are_bit_identical():
-    """forms 93 / 94 differ only in how far ahead the weight fragments are requested; the library's own choice (form 0) is one of them"""
+    """forms 93 / 94 differ only in how far ahead the weight fragments are requested, form 95 (round 6) in the channels a wave owns (32
+    instead of 64: twice the workgroups, what the library picks for launches of <= 128 workgroups); the library's own choice (form 0)
+    is one of them -- 95 for the first three shapes here, 93 for the last"""
     from multiagentperception_amd import ops
-    for cin, cout, H, W, M in ((512, 512, 16, 16, 5), (256, 256, 32, 32, 2), (512, 256, 16, 16, 3)):
+    for cin, cout, H, W, M in ((512, 512, 16, 16, 5), (256, 256, 32, 32, 2), (512, 256, 16, 16, 3), (256, 256, 32, 32, 6)):
         case = (93, M, H, W, cin, cout, 1, True, True, 0, 0)
         xs, ws, scale, shift, ress, x_dev, w_dev, res_dev = _wreg_setup(case, 5 + cin + cout)
         wfrag = ops.pack_wfrag_device(w_dev, cin)
         sc, sh = scale.to(_dev()), shift.to(_dev())
         ref = ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, residual=res_dev, form=93).clone()
-        for form in (94, 0):
+        for form in (94, 95, 0):
             for _ in range(10):
                 assert torch.equal(ops.conv3x3_wreg(x_dev, 0, cin, wfrag, cout, 1, sc, sh, residual=res_dev, form=form), ref), form
 
