@@ -803,8 +803,10 @@ class CommEngine:
         program, io = entry
         packc = torch.empty_like(program.result)
         io.update(x=x, out=out, pack=packc, gt=gt, hist=hist)     # what the host-issued regions of this replay read and write
-        program.replay()
-        io.update(x=None, out=None, pack=None, gt=None, hist=None)
+        try:
+            program.replay()
+        finally:
+            io.update(x=None, out=None, pack=None, gt=None, hist=None)
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, N)
         return out, prob, action, nnz
 

@@ -313,8 +313,10 @@ class AgentParallelForward:
         program, io = ent
         packc = torch.empty_like(program.result)
         io.update(x=x, out=out, pack=packc)
-        program.replay()
-        io.update(x=None, out=None, pack=None)
+        try:
+            program.replay()
+        finally:
+            io.update(x=None, out=None, pack=None)
         self.launch_form = "one program: %d single-branch hip-graphs + %d host-issued steps incl. the RCCL all-gathers" % (program.n_graphs, program.n_calls)
         prob, action, nnz = ops.carve_graph_outputs(packc, B, N, n_loc)
         return out, prob, action, nnz
