@@ -27,39 +27,62 @@ def _cfg(n, size):
     return {"model": model, "data": {"img_rows": size, "img_cols": size}}
 
 
-def _worker(rank, world, port, N, B, S, seed, mode, out_dir, graph=False, precision="bf16"):
+# (mode, graph replay, trunk precision, seed) of every two-rank forward checked below.  ONE pair of rank processes runs them all (a
+# spawn = two interpreter starts + two `import torch`: ~8 s each, seven of them were a seventh of the suite): a fresh model per job,
+# as when every job had its own processes.
+_FWD_JOBS = [("softmax", False, "bf16", 321), ("softmax", True, "bf16", 321), ("activated", False, "bf16", 321),
+             ("activated", True, "bf16", 321), ("argmax_test", False, "bf16", 321), ("softmax", False, "fp8", 99), ("softmax", True, "fp8", 99)]
+
+
+def _worker(rank, world, port, N, B, S, jobs, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(400, exit=True)          # a hung collective must not hold the GPU box
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import filler
     from ptsemseg.models import get_model
     from multiagentperception_amd.parallel import AgentParallelForward, shard_agents
-    model = get_model(_cfg(N, S), 11)
-    filler.apply_to_module(model)
-    model = model.to("cuda:0").eval()
-    model.set_trunk_precision(precision)
-    q_lo, n_loc = shard_agents(N, world, rank)
-    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
-    fwd = AgentParallelForward(model)
-    model.use_hip_graph = graph
-    if graph and precision == "bf16":   # capture on OTHER frames first, so the checked call is a pure replay through the static buffers
-        other = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed + 1))
-        fwd(other[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
-    pred, prob, action, nnz = fwd(x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
-    torch.cuda.synchronize()
-    torch.save(dict(pred=pred.cpu(), prob=prob.cpu(), action=action.cpu(), q_lo=q_lo, n_loc=n_loc,
-                    exch=getattr(fwd, "last_exchange", None)), os.path.join(out_dir, "r%d.pt" % rank))
-    dist.barrier()
+    for j, (mode, graph, precision, seed) in enumerate(jobs):
+        model = get_model(_cfg(N, S), 11)
+        filler.apply_to_module(model)
+        model = model.to("cuda:0").eval()
+        model.set_trunk_precision(precision)
+        q_lo, n_loc = shard_agents(N, world, rank)
+        x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
+        fwd = AgentParallelForward(model)
+        model.use_hip_graph = graph
+        if graph and precision == "bf16":   # capture on OTHER frames first, so the checked call is a pure replay through the static buffers
+            other = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed + 1))
+            fwd(other[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
+        pred, prob, action, nnz = fwd(x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(), inference=mode)
+        torch.cuda.synchronize()
+        torch.save(dict(pred=pred.cpu(), prob=prob.cpu(), action=action.cpu(), q_lo=q_lo, n_loc=n_loc,
+                        exch=getattr(fwd, "last_exchange", None)), os.path.join(out_dir, "j%d_r%d.pt" % (j, rank)))
+        del fwd, model
+        dist.barrier()
     dist.destroy_process_group()
+
+
+_FWD_GEOM = (2, 4, 2, 128)                  # world, N, B, S
+
+
+@pytest.fixture(scope="module")
+def two_rank_forwards(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("two_rank_forwards"))
+    world, N, B, S = _FWD_GEOM
+    mp.spawn(_worker, args=(world, _free_port(), N, B, S, _FWD_JOBS, out), nprocs=world, join=True)
+    return out
 
 
 @pytest.mark.parametrize("mode,graph", [("softmax", False), ("softmax", True), ("activated", False), ("activated", True),
                                         ("argmax_test", False)])
-def test_two_rank_agent_parallel_forward_equals_unsharded(tmp_path, mode, graph):
+def test_two_rank_agent_parallel_forward_equals_unsharded(two_rank_forwards, mode, graph):
     from oracle import filler
     from ptsemseg.models import get_model
-    world, N, B, S, seed = 2, 4, 2, 128, 321
-    mp.spawn(_worker, args=(world, _free_port(), N, B, S, seed, mode, str(tmp_path), graph), nprocs=world, join=True)
+    world, N, B, S = _FWD_GEOM
+    j = _FWD_JOBS.index((mode, graph, "bf16", 321))
+    seed = _FWD_JOBS[j][3]
     model = get_model(_cfg(N, S), 11)
     filler.apply_to_module(model)
     model = model.to("cuda:0").eval()
@@ -67,7 +90,7 @@ def test_two_rank_agent_parallel_forward_equals_unsharded(tmp_path, mode, graph)
     pred, prob, action, _ = model(x, training=False, MO_flag=True, inference=mode)
     pred, prob, action = pred.cpu(), prob.cpu(), action.cpu()
     for r in range(world):
-        d = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        d = torch.load(os.path.join(two_rank_forwards, "j%d_r%d.pt" % (j, r)))
         lo, n = d["q_lo"], d["n_loc"]
         # bit for bit: the exchange is exact, every conv variant walks K in the same order and the
         # split-K plan depends on the layer only, so a rank's 2 agents round exactly like the same agents inside the
@@ -188,28 +211,33 @@ def test_thresholded_modes_through_the_one_graph_sharded_step_equal_the_plain_fo
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_two_rank_fp8_trunk_quantises_alike_on_every_rank(tmp_path, graph):
+def test_two_rank_fp8_trunk_quantises_alike_on_every_rank(two_rank_forwards, graph):
     """fp8 value encoder, sharded: the calibration amax is all-reduced (MAX) over the ranks, so every rank uses the scales the
     unsharded batch would have calibrated (amax of a union = max of the amaxes) and the shard is bit-identical again."""
     from oracle import filler
     from ptsemseg.models import get_model
-    world, N, B, S, seed = 2, 4, 2, 128, 99
-    mp.spawn(_worker, args=(world, _free_port(), N, B, S, seed, "softmax", str(tmp_path), graph, "fp8"), nprocs=world, join=True)
+    world, N, B, S = _FWD_GEOM
+    j = _FWD_JOBS.index(("softmax", graph, "fp8", 99))
+    seed = _FWD_JOBS[j][3]
     model = get_model(_cfg(N, S), 11)
     filler.apply_to_module(model)
     model = model.to("cuda:0").eval().set_trunk_precision("fp8")
     x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed)).cuda()
     pred, prob, action, _ = model(x, training=False, MO_flag=True, inference="softmax")
     for r in range(world):
-        d = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        d = torch.load(os.path.join(two_rank_forwards, "j%d_r%d.pt" % (j, r)))
         lo, n = d["q_lo"], d["n_loc"]
         assert torch.equal(d["prob"], prob.cpu()[:, :, lo:lo + n])
         assert torch.equal(d["pred"], pred.cpu()[lo * B:(lo + n) * B])
 
 
-def _train_worker(rank, world, port, arch, N, B, S, seed, out_dir):
+_TRAIN_GEOM = (2, 4, 1, 128, 77)           # world, N, B, S, seed
+_TRAIN_ARCHS = ["MIMOcom", "MIMOcomWho"]
+
+
+def _train_worker(rank, world, port, archs, N, B, S, seed, out_dir):
     import faulthandler
-    faulthandler.dump_traceback_later(150, exit=True)          # a collective mismatch would hang both ranks: die with a traceback instead
+    faulthandler.dump_traceback_later(300, exit=True)          # a collective mismatch would hang both ranks: die with a traceback instead
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -219,29 +247,39 @@ def _train_worker(rank, world, port, arch, N, B, S, seed, out_dir):
     from multiagentperception_amd.loss import cross_entropy2d
     from multiagentperception_amd.parallel import agent_parallel_train_step, shard_agents
     train_ops.set_train_backend("hip")
-    cfg = _cfg(N, S)
-    cfg["model"]["arch"] = arch
-    cfg["model"]["query"] = arch == "MIMOcom"
-    model = get_model(cfg, 11)
-    filler.apply_to_module(model)
-    model = model.to("cuda:0").train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.0)
-    q_lo, n_loc = shard_agents(N, world, rank)
-    x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
-    labels = torch.from_numpy(filler.synthetic_labels(B * N, S, S, seed))
-    labels[:B, :S // 2] = 250                 # ignored pixels on rank 0 only: the ranks' denominators differ (global denominator)
-    loss = agent_parallel_train_step(model, opt, cross_entropy2d, x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(),
-                                     labels[q_lo * B:(q_lo + n_loc) * B].cuda())
-    torch.cuda.synchronize()
-    if rank == 0:
-        torch.save(dict(loss=float(loss), grads={k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}),
-                   os.path.join(out_dir, "train.pt"))
-    dist.barrier()
+    for arch in archs:                        # one pair of rank processes for both model families (see _FWD_JOBS)
+        cfg = _cfg(N, S)
+        cfg["model"]["arch"] = arch
+        cfg["model"]["query"] = arch == "MIMOcom"
+        model = get_model(cfg, 11)
+        filler.apply_to_module(model)
+        model = model.to("cuda:0").train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        q_lo, n_loc = shard_agents(N, world, rank)
+        x = torch.from_numpy(filler.synthetic_frames(B, N, S, S, seed))
+        labels = torch.from_numpy(filler.synthetic_labels(B * N, S, S, seed))
+        labels[:B, :S // 2] = 250             # ignored pixels on rank 0 only: the ranks' denominators differ (global denominator)
+        loss = agent_parallel_train_step(model, opt, cross_entropy2d, x[:, 3 * q_lo:3 * (q_lo + n_loc)].contiguous().cuda(),
+                                         labels[q_lo * B:(q_lo + n_loc) * B].cuda())
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save(dict(loss=float(loss), grads={k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}),
+                       os.path.join(out_dir, "train_%s.pt" % arch))
+        del model, opt
+        dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch", ["MIMOcom", "MIMOcomWho"])
-def test_two_rank_agent_sharded_training_step_matches_the_one_gpu_step(tmp_path, arch):
+@pytest.fixture(scope="module")
+def two_rank_train_steps(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("two_rank_train"))
+    world, N, B, S, seed = _TRAIN_GEOM
+    mp.spawn(_train_worker, args=(world, _free_port(), _TRAIN_ARCHS, N, B, S, seed, out), nprocs=world, join=True)
+    return out
+
+
+@pytest.mark.parametrize("arch", _TRAIN_ARCHS)
+def test_two_rank_agent_sharded_training_step_matches_the_one_gpu_step(two_rank_train_steps, arch):
     """Round 4 (SURVEY 8f rank 3 + 8e caveat): agents sharded over 2 ranks IN TRAINING -- cross-rank BatchNorm statistics (forward and
     backward sums all-reduced), differentiable all-gather of value maps and keys, gradients all-reduced in one bucket -- against the
     same step on one GPU with all agents.  Same bf16 activation flow, same kernels; the sums only differ in order (f64), so loss and
@@ -251,9 +289,8 @@ def test_two_rank_agent_sharded_training_step_matches_the_one_gpu_step(tmp_path,
     from ptsemseg.models import get_model
     from multiagentperception_amd import train_ops
     from multiagentperception_amd.loss import cross_entropy2d
-    world, N, B, S, seed = 2, 4, 1, 128, 77
-    mp.spawn(_train_worker, args=(world, _free_port(), arch, N, B, S, seed, str(tmp_path)), nprocs=world, join=True)
-    d = torch.load(os.path.join(str(tmp_path), "train.pt"))
+    world, N, B, S, seed = _TRAIN_GEOM
+    d = torch.load(os.path.join(two_rank_train_steps, "train_%s.pt" % arch))
     train_ops.set_train_backend("hip")
     cfg = _cfg(N, S)
     cfg["model"]["arch"] = arch
