@@ -292,7 +292,7 @@ def main():
     ap.add_argument("--no-retry", action="store_true", help="report a host-stalled run as it is (see the slow-launch guard in main)")
     ap.add_argument("--mode", default="softmax", choices=["softmax", "argmax_test", "activated"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
-    ap.add_argument("--inflight", type=int, default=3, help="side figure: throughput with this many forwards in flight (1 = skip)")
+    ap.add_argument("--inflight", type=int, default=2, help="side figure: throughput with this many forwards in flight (1 = skip)")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3, MX-scaled MFMA) trunk convs")
     ap.add_argument("--bf16", action="store_true", help="force the bf16 trunk (cfg5 defaults to fp8)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -651,7 +651,9 @@ def main():
     # ---- throughput with several forwards in flight (a serving loop), reported beside the headline, never as `value` ---
     # F engines with their own activation buffers and captured graphs, one stream each, launched round-robin: the latency-bound tail of
     # one forward (heads, graph, decoder: a nearly idle chip) runs beside the next forward's trunk.  The headline keeps one forward
-    # at a time (its ms_per_step is a latency); tools/pipeline2.py is the same loop stand-alone.
+    # at a time (its ms_per_step is a latency); tools/pipeline2.py is the same loop stand-alone.  Default F = 2: two caller streams + the
+    # engines' shared value lane + the null stream are the runtime's four hardware queues (round 6, one box: F = 1 0.988, F = 2 0.918,
+    # F = 3 1.058 ms per forward -- a fifth stream shares a hardware queue with another and their chains serialise).
     if world == 1 and not args.force_sharded and model.use_hip_graph and args.inflight > 1:
         F = args.inflight
         extra = []

@@ -276,7 +276,12 @@ class _CapStreams:
         self.dev = dev
 
     def __getitem__(self, lane):
-        return _lane_stream(self.dev, "cap%d" % lane)
+        # lane 0 is captured on one extra stream ("cap0", also the warm-up stream), a side lane on that lane's own long-lived stream: the
+        # package makes TWO streams per thread and device in all.  The runtime spreads streams over four hardware queues in creation order;
+        # every further stream of ours is one more chance that a caller's stream shares a queue with the value lane, and then the two
+        # chains of a forward run one behind the other (bench.py's forwards_in_flight, two engines on two caller streams: 1.10 ms per
+        # forward with three capture streams made ahead of the callers', 0.92 with the callers' streams made first)
+        return _lane_stream(self.dev, "cap0" if lane == 0 else lane)
 
 
 class _Recorder:

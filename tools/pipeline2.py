@@ -1,5 +1,5 @@
 """Throughput experiment: F forwards in flight (F engines with their own buffers / captured graphs, one stream each, launched
-round-robin) against the one-forward-at-a-time headline.   python tools/pipeline2.py [F ...]"""
+round-robin) against the one-forward-at-a-time headline.   python tools/pipeline2.py [--eager] [F ...]"""
 import os
 import sys
 import time
@@ -13,7 +13,8 @@ from ptsemseg.models import get_model  # noqa: E402
 
 
 def main():
-    fs = [int(a) for a in sys.argv[1:]] or [1, 2, 3]
+    eager = "--eager" in sys.argv
+    fs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 3]
     dev = torch.device("cuda:0")
     preset = bench.PRESETS["cfg2"]
     B, n, S = preset["batch"], preset["agents"], preset["size"]
@@ -22,12 +23,12 @@ def main():
         filler.apply_to_module(m)                  # deterministic filler: every copy has the same weights
         return m.to(dev).eval()
     x = torch.from_numpy(filler.synthetic_frames(B, n, S, S, 1234 + 2)).to(dev)
-    steps = 40
+    steps = 300
     for F in fs:
         models = [make() for _ in range(F)]
         streams = [torch.cuda.Stream(dev) for _ in range(F)]
         for m in models:
-            m.use_hip_graph = True
+            m.use_hip_graph = not eager
         for i in range(3 * F):
             with torch.cuda.stream(streams[i % F]):
                 out = models[i % F](x, training=False, MO_flag=True, inference="softmax")
