@@ -270,14 +270,15 @@ class AgentParallelForward:
         # back.  A third stream is one more draw in the runtime's stream -> hardware-queue assignment (profiles/r06_stream_queues.txt): when
         # the group's stream lands on the caller's queue the U gather queues behind the whole policy chain.  One-rank proxy, ms per step,
         # interleaved: cfg 2 1.0001 / 1.0007 -> 0.9754 / 0.9753, cfg-3 rank 0.5690 / 0.5657 -> 0.5529 / 0.5481.  The issue order (U, then K)
-        # is the same on every rank; the library orders consecutive operations of one communicator across streams.  gloo (the CPU-side
-        # tests) keeps the asynchronous form: its synchronous calls block the host.
+        # is the same on every rank, and K is enqueued behind an event recorded after U (policy_tail): two operations of one communicator
+        # never run side by side.  gloo (the CPU-side tests) keeps the asynchronous form: its synchronous calls block the host.
         _GS = dist.get_backend(self.group) == "nccl"
 
         def step(io):
             # io: this run's caller-owned tensors; the host-issued regions (stem, join) read them at every replay as plain arguments
             L = ops.lanes(dev)
             works = []
+            u_done = []
             L.eager(lambda: eng.trunk.stem(io["x"], n_loc, out=st.s0))      # host-issued at every replay (engine.TrunkPlan.after_stem says why)
 
             def value_tail(v):
@@ -286,12 +287,19 @@ class AgentParallelForward:
                 # under the policy tail.  after_stem hands the value chain its launches first, the policy chain's second.
                 u = eng.value_maps(v, out=st.v_slot, out_own=st.u_own)
                 L.eager(lambda: works.append(_gather_inplace(st.v_all, self.rank, rows, self.group, sync=_GS)))
+                if _GS:
+                    u_done.append(L.mark())          # (behind the U gather on the value lane: see policy_tail)
                 return u
 
             def policy_tail(pol):
                 # (lane 0)
                 y = eng.policy_convs(pol, ch_off=0)
                 eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
+                if _GS and u_done:
+                    # one communicator, two streams: the library's contract leaves it to the caller that two of its operations never run
+                    # side by side -- K is enqueued behind the END of the U gather (an event edge; with the group's single stream they
+                    # were serialised in the same order).  U is long done by then unless the links are the bottleneck.
+                    L.wait(u_done[-1])
                 L.eager(lambda: works.append(_gather_inplace(st.k_all, self.rank, rows, self.group, sync=_GS)))
                 return y
 
