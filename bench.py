@@ -604,8 +604,8 @@ def main():
         result["comm"] = dict(backend=("rccl" if args.backend == "nccl" else "gloo"), ranks=world,
                               us_per_step_unoverlapped=round(comm_us, 1),
                               v_shard_bytes=int(st.v_slot.numel() * st.v_slot.element_size()), k_shard_bytes=int(st.k_slot.numel() * 4),
-                              note="all-gather of V (bf16, written in place by the squeezer) + projected keys; in the timed "
-                                   "step the V gather runs under the policy tail")
+                              note="all-gather of U (f32: the decoder's first conv of the value maps, written in place) + projected keys; in the "
+                                   "timed step the U gather runs on the value lane under the policy tail")
 
     # ---- the same step with eager launches (model.use_hip_graph = False: every launch issued by the host as the Python code runs),
     # reported beside the headline, never as `value` ---
