@@ -652,8 +652,9 @@ def main():
     # F engines with their own activation buffers and captured graphs, one stream each, launched round-robin: the latency-bound tail of
     # one forward (heads, graph, decoder: a nearly idle chip) runs beside the next forward's trunk.  The headline keeps one forward
     # at a time (its ms_per_step is a latency); tools/pipeline2.py is the same loop stand-alone.  Default F = 2: two caller streams + the
-    # engines' shared value lane + the null stream are the runtime's four hardware queues (round 6, one box: F = 1 0.988, F = 2 0.918,
-    # F = 3 1.058 ms per forward -- a fifth stream shares a hardware queue with another and their chains serialise).
+    # engines' shared value lane + the null stream are the runtime's four hardware queues; the caller streams are picked by
+    # ops.caller_streams so that none shares a queue with another or with the value lane (streams as they come: 0.92 ... 1.10 ms per forward
+    # depending on the draw; picked: 0.930 / 0.928 against 0.9935 one at a time).
     if world == 1 and not args.force_sharded and model.use_hip_graph and args.inflight > 1:
         F = args.inflight
         extra = []
@@ -665,7 +666,8 @@ def main():
             _apply_precision(m2, args)
             extra.append(m2)
         models = [model] + extra
-        streams = [torch.cuda.Stream(dev) for _ in range(F)]
+        from multiagentperception_amd import ops as _ops
+        streams = _ops.caller_streams(dev, F)       # on hardware queues of their own (and not the value lane's): ops.streams_share_queue
         outs = [None] * F
         for i in range(3 * F):
             with torch.cuda.stream(streams[i % F]):

@@ -396,6 +396,54 @@ class _Recorder:
         return res
 
 
+def streams_share_queue(a, b, spin_cycles=300000):
+    """Do torch streams a and b of one device run on the same hardware queue?  (The runtime multiplexes streams on four; two streams of
+    one queue run their work one behind the other -- a caller's stream on the value lane's queue turns the forward's two chains into
+    one.)  Probe: a ~150 us spin on one stream, a trivial kernel on the other issued right behind it; if that kernel ends only after the
+    spin, they share.  Both directions.  Synchronises the device; never call it inside a capture.  False when torch has no spin kernel."""
+    spin = getattr(torch.cuda, "_sleep", None)
+    if spin is None or a == b:
+        return a == b
+    x = torch.zeros(64, device=a.device)
+    torch.cuda.synchronize(a.device)
+
+    def held(p, q):
+        e0, e1, eq = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(p):
+            e0.record()
+            spin(int(spin_cycles))
+            e1.record()
+        with torch.cuda.stream(q):
+            x.add_(1.0)
+            eq.record()
+        torch.cuda.synchronize(a.device)
+        return e0.elapsed_time(eq) > 0.7 * e0.elapsed_time(e1)
+    held(a, b)                                      # (first use of a stream: not timed)
+    return held(a, b) or held(b, a)
+
+
+def caller_streams(dev, n, tries=12):
+    """n new streams for a loop that keeps n engines in flight: mutually on different hardware queues, and none on the queue of this
+    thread's value lane (lane 1), as far as `tries` candidates allow (the rest are taken as they come).  The rejected candidates stay
+    alive with the returned list's first element (a destroyed stream would hand its queue slot to the next one made)."""
+    dev = torch.device(dev)
+    lane = _lane_stream(dev, 1)
+    chosen, rejected = [], []
+    for _ in range(tries):
+        if len(chosen) == n:
+            break
+        c = torch.cuda.Stream(device=dev)
+        if any(streams_share_queue(c, o) for o in [lane] + chosen):
+            rejected.append(c)
+        else:
+            chosen.append(c)
+    while len(chosen) < n:
+        chosen.append(rejected.pop() if rejected else torch.cuda.Stream(device=dev))
+    if chosen:
+        chosen[0]._w2c_keepalive = rejected
+    return chosen
+
+
 def lanes(dev):
     """the lanes executor in effect on this thread: the recorder inside record_program(), else stream / event calls"""
     rec = getattr(_tls, "recorder", None)

@@ -192,3 +192,22 @@ def test_a_nested_recording_is_refused_and_a_failed_recording_leaves_no_capture_
         ops.record_program(dev, lambda: ops.record_program(dev, lambda: x + 1, warmup=0), warmup=0)
     prog = ops.record_program(dev, lambda: x + 2, warmup=0)                # and recording still works afterwards
     assert float(prog.replay()[0]) == 2.0
+
+
+def test_caller_streams_are_distinct_streams_and_the_queue_probe_runs():
+    """ops.caller_streams (round 6: streams for a loop that keeps several engines in flight, picked so that they share no hardware queue
+    with each other or with the value lane -- bench.py's forwards_in_flight) returns n distinct streams; ops.streams_share_queue answers
+    True for a stream and itself and a bool for any pair.  (Which pairs share is the runtime's draw: profiles/r06_stream_queues.txt.)"""
+    import torch
+    from multiagentperception_amd import ops
+    dev = torch.device("cuda:0")
+    ss = ops.caller_streams(dev, 3)
+    assert len(ss) == 3 and len({s.cuda_stream for s in ss}) == 3 and all(isinstance(s, torch.cuda.Stream) for s in ss)
+    assert ops.streams_share_queue(ss[0], ss[0]) is True
+    assert ops.streams_share_queue(ss[0], ss[1]) in (True, False)
+    x = torch.ones(16, device=dev)
+    with torch.cuda.stream(ss[2]):
+        y = x * 2
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 32.0
+

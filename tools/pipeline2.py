@@ -26,7 +26,8 @@ def main():
     steps = 300
     for F in fs:
         models = [make() for _ in range(F)]
-        streams = [torch.cuda.Stream(dev) for _ in range(F)]
+        from multiagentperception_amd import ops
+        streams = ops.caller_streams(dev, F) if "--pick" in sys.argv else [torch.cuda.Stream(dev) for _ in range(F)]
         for m in models:
             m.use_hip_graph = not eager
         for i in range(3 * F):
