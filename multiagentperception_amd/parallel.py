@@ -106,15 +106,14 @@ def shard_agents(agent_num, world, rank):
     return rank * n_loc, n_loc
 
 
-def _gather_inplace(buf, rank, rows, group=None, sync=False):
+def _gather_inplace(buf, rank, rows, group=None):
     """all-gather where every rank's shard already sits in its own rows [rank*rows, (rank+1)*rows) of `buf` (the
     producing kernels wrote it there: no staging copy).  RCCL does this in place; other backends (gloo in the tests)
-    get a private copy of the shard as the send buffer.  Returns the async work handle, or None with sync=True (the collective is then
-    enqueued on torch's current stream)."""
+    get a private copy of the shard as the send buffer.  Returns the async work handle."""
     mine = buf[rank * rows:(rank + 1) * rows]
     if dist.get_backend(group) != "nccl":
         mine = mine.clone()
-    return dist.all_gather_into_tensor(_as_bytes_view(buf), _as_bytes_view(mine), group=group, async_op=not sync)
+    return dist.all_gather_into_tensor(_as_bytes_view(buf), _as_bytes_view(mine), group=group, async_op=True)
 
 
 class _ShardState:
@@ -265,20 +264,10 @@ class AgentParallelForward:
         rows = n_loc * B
         out = torch.empty((n_loc * B, eng.n_classes, H, W), dtype=torch.float32, device=dev)
 
-        # RCCL: the two all-gathers are SYNCHRONOUS collectives -- torch enqueues those on the CURRENT stream, i.e. on the lane that produced
-        # the shard (U on the value lane, K on the caller's stream), instead of on the process group's own stream with an event hop there and
-        # back.  A third stream is one more draw in the runtime's stream -> hardware-queue assignment (profiles/r06_stream_queues.txt): when
-        # the group's stream lands on the caller's queue the U gather queues behind the whole policy chain.  One-rank proxy, ms per step,
-        # interleaved: cfg 2 1.0001 / 1.0007 -> 0.9754 / 0.9753, cfg-3 rank 0.5690 / 0.5657 -> 0.5529 / 0.5481.  The issue order (U, then K)
-        # is the same on every rank, and K is enqueued behind an event recorded after U (policy_tail): two operations of one communicator
-        # never run side by side.  gloo (the CPU-side tests) keeps the asynchronous form: its synchronous calls block the host.
-        _GS = dist.get_backend(self.group) == "nccl"
-
         def step(io):
             # io: this run's caller-owned tensors; the host-issued regions (stem, join) read them at every replay as plain arguments
             L = ops.lanes(dev)
             works = []
-            u_done = []
             L.eager(lambda: eng.trunk.stem(io["x"], n_loc, out=st.s0))      # host-issued at every replay (engine.TrunkPlan.after_stem says why)
 
             def value_tail(v):
@@ -286,21 +275,14 @@ class AgentParallelForward:
                 # gather (which waits for the end of the policy tail) must not be queued ahead of the U gather, or U would not travel
                 # under the policy tail.  after_stem hands the value chain its launches first, the policy chain's second.
                 u = eng.value_maps(v, out=st.v_slot, out_own=st.u_own)
-                L.eager(lambda: works.append(_gather_inplace(st.v_all, self.rank, rows, self.group, sync=_GS)))
-                if _GS:
-                    u_done.append(L.mark())          # (behind the U gather on the value lane: see policy_tail)
+                L.eager(lambda: works.append(_gather_inplace(st.v_all, self.rank, rows, self.group)))
                 return u
 
             def policy_tail(pol):
                 # (lane 0)
                 y = eng.policy_convs(pol, ch_off=0)
                 eng.policy_heads(y, outs=(st.k_slot, st.q_loc))
-                if _GS and u_done:
-                    # one communicator, two streams: the library's contract leaves it to the caller that two of its operations never run
-                    # side by side -- K is enqueued behind the END of the U gather (an event edge; with the group's single stream they
-                    # were serialised in the same order).  U is long done by then unless the links are the bottleneck.
-                    L.wait(u_done[-1])
-                L.eager(lambda: works.append(_gather_inplace(st.k_all, self.rank, rows, self.group, sync=_GS)))
+                L.eager(lambda: works.append(_gather_inplace(st.k_all, self.rank, rows, self.group)))
                 return y
 
             eng.trunk.after_stem(st.s0, squeezer_out=[st.v_loc, st.pol], policy_next=(policy_tail, lambda y: y), value_next=value_tail)
